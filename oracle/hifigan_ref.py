@@ -1,0 +1,65 @@
+"""Oracle: HiFi-GAN V1 generator.  TEST INFRASTRUCTURE (see oracle/__init__.py).
+
+PARITY UNPINNED: the reference only holds a handle (hifigan.py:106-110, 180:
+``HIFIGAN.from_hparams(...).decode_batch(mel)``); the generator lives in SpeechBrain, which is
+absent.  This restates the published V1 generator (Kong et al. 2020, ``models.py::Generator`` with
+``ResBlock1``; weight-norm folded) with ``torch.nn.functional`` ops.  SpeechBrain wraps the same
+graph; its conv wrappers' padding mode cannot be verified offline, so it is a parameter here
+(``"zeros"`` = the published model)."""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+
+def _conv1d(x, w, b, dilation=1, padding_mode="zeros"):
+    k = w.shape[-1]
+    pad = (k * dilation - dilation) // 2
+    if padding_mode == "zeros":
+        return F.conv1d(x, w, b, padding=pad, dilation=dilation)
+    return F.conv1d(F.pad(x, (pad, pad), mode=padding_mode), w, b, dilation=dilation)
+
+
+def resblock1(x, sd, p, dilations, slope, padding_mode):
+    """ResBlock1: for each dilation d: x += conv2(lrelu(conv1_d(lrelu(x))))."""
+    for i, d in enumerate(dilations):
+        xt = F.leaky_relu(x, slope)
+        xt = _conv1d(xt, sd[p + f"convs1.{i}.weight"], sd[p + f"convs1.{i}.bias"], d, padding_mode)
+        xt = F.leaky_relu(xt, slope)
+        xt = _conv1d(xt, sd[p + f"convs2.{i}.weight"], sd[p + f"convs2.{i}.bias"], 1, padding_mode)
+        x = xt + x
+    return x
+
+
+def generator(mel: torch.Tensor, sd, cfg, padding_mode: str = "zeros") -> torch.Tensor:
+    """``mel [B, 80, T] -> wav [B, 1, T*256]``."""
+    x = _conv1d(mel, sd["conv_pre.weight"], sd["conv_pre.bias"], 1, padding_mode)
+    nk = len(cfg.resblock_kernel_sizes)
+    for i, (r, k) in enumerate(zip(cfg.upsample_rates, cfg.upsample_kernel_sizes)):
+        x = F.leaky_relu(x, cfg.leaky_slope)
+        x = F.conv_transpose1d(x, sd[f"ups.{i}.weight"], sd[f"ups.{i}.bias"], stride=r, padding=(k - r) // 2)
+        xs = None
+        for j in range(nk):
+            y = resblock1(x, sd, f"resblocks.{i * nk + j}.", cfg.resblock_dilations, cfg.leaky_slope, padding_mode)
+            xs = y if xs is None else xs + y
+        x = xs / nk
+    x = F.leaky_relu(x)                      # default slope 0.01, as published
+    x = _conv1d(x, sd["conv_post.weight"], sd["conv_post.bias"], 1, padding_mode)
+    return torch.tanh(x)
+
+
+def align_waveforms(ref_wav: torch.Tensor, deg_wav: torch.Tensor):
+    """hifigan.py:113-136 -- full cross-correlation by conv1d, argmax shift, trim to common length."""
+    ref_wav = ref_wav.view(1, 1, -1)
+    deg_wav = deg_wav.view(1, 1, -1)
+    padding = deg_wav.shape[-1]
+    cc = F.conv1d(F.pad(ref_wav, (padding, padding)), deg_wav)
+    shift = int(torch.argmax(cc).item()) - padding
+    if shift > 0:
+        ref_a = ref_wav[..., shift:]
+        deg_a = deg_wav[..., : ref_a.shape[-1]]
+    else:
+        deg_a = deg_wav[..., -shift:]
+        ref_a = ref_wav[..., : deg_a.shape[-1]]
+    n = min(ref_a.shape[-1], deg_a.shape[-1])
+    return ref_a[..., :n], deg_a[..., :n]
