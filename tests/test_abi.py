@@ -1,0 +1,49 @@
+"""CPU-only: the C-ABI library builds, loads and exports every symbol include/addvisor_hip.h declares."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+from addvisor_hip import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "addvisor_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(advh_[a-z0-9_]+)\s*\(", text)))
+
+
+@pytest.fixture(scope="module")
+def built():
+    return _lib.build()
+
+
+def test_header_matches_bindings():
+    assert declared_symbols() == sorted(_lib.SIGNATURES)
+
+
+def test_library_exports_every_symbol(built):
+    lib = ctypes.CDLL(built)
+    for name in declared_symbols():
+        assert hasattr(lib, name), name
+    assert b"gfx950" in _lib.lib().advh_version()
+
+
+def test_code_object_is_gfx950(built):
+    out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "--offloading", built],
+                         capture_output=True, text=True).stdout
+    assert "gfx950" in out
+
+
+def test_no_oracle_import_in_product():
+    """The product path must never route through the oracle (or any CPU fallback)."""
+    pkg = os.path.join(ROOT, "xai-audio-deepfakes_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith(".py"):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f

@@ -1,0 +1,75 @@
+"""ctypes binding of ``libaddvisor_hip.so`` (include/addvisor_hip.h).
+
+The library is the product: if it is missing or fails to load this module raises -- there is no
+CPU or eager-PyTorch fallback anywhere in the package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libaddvisor_hip.so")
+CSRC = os.path.join(os.path.dirname(_HERE), "csrc")
+
+ERRORS = {-1: "ADVH_EINVAL (bad argument)", -2: "ADVH_ELAUNCH (HIP launch failed)",
+          -3: "ADVH_ENOTINIT (advh_init not called)", -4: "ADVH_EUNSUPPORTED"}
+
+
+class AdvhError(RuntimeError):
+    pass
+
+
+def build(verbose: bool = False) -> str:
+    """Compile every HIP source for gfx950 (``make -C csrc``); hipcc cross-compiles without a GPU."""
+    r = subprocess.run(["make", "-C", CSRC, "-j8"], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise AdvhError("building libaddvisor_hip.so failed:\n" + r.stdout[-4000:] + r.stderr[-4000:])
+    if verbose:
+        print(r.stdout)
+    return LIB_PATH
+
+
+_p, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
+
+# name -> (restype, argtypes): exactly the symbols include/addvisor_hip.h declares
+SIGNATURES = {
+    "advh_version": (C.c_char_p, []),
+    "advh_init": (_i, []),
+    "advh_stft_forward": (_i, [_p, _i64, _i, _i, _i, _i, _i, _p, _p, _p, _p, _i, _p]),
+    "advh_istft_masked": (_i, [_p, _p, _p, _i, _i, _i, _p, _p, _i64, _i, _i, _i, _i, _i, _p, _p]),
+    "advh_istft_c64": (_i, [_p, _p, _i64, _i, _i, _i, _i, _i, _p, _p]),
+}
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise AdvhError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                            "(there is no fallback path)")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)          # AttributeError if the header and the library disagree
+            fn.restype, fn.argtypes = res, args
+        _lib = l
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise AdvhError(f"{what}: {ERRORS.get(rc, rc)}")
+
+
+_inited = False
+
+
+def init() -> None:
+    """advh_init() on the current device (twiddle tables, LDS limits)."""
+    global _inited
+    if not _inited:
+        check(lib().advh_init(), "advh_init")
+        _inited = True

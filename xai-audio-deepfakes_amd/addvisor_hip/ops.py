@@ -1,0 +1,110 @@
+"""Torch-tensor front ends of the C-ABI entry points.
+
+PyTorch is plumbing here: it owns device memory (caching allocator) and the current HIP stream.
+Every function checks shapes / dtypes / contiguity on the host before a raw pointer reaches a
+hand-written kernel, launches on ``torch.cuda.current_stream()`` and returns torch tensors.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+
+NFFT = 1024
+NBIN = 513
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _req(t: torch.Tensor, dtype, name: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise ValueError(f"{name} must be a CUDA (HIP) tensor")
+    if t.dtype != dtype:
+        raise ValueError(f"{name} must be {dtype}, got {t.dtype}")
+    return t.contiguous()
+
+
+def stft_forward(wave: torch.Tensor, length: int, hop: int = 322, win: int = 644,
+                 window: Optional[torch.Tensor] = None, want_complex: bool = True,
+                 want_mag: bool = True, want_phase: bool = True
+                 ) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor], Optional[torch.Tensor]]:
+    """``wave [B, n_in]`` fp32 -> ``X [B,513,T] complex64, |X|, angle(X) [B,513,T]`` (audioprocessor.py:82-112).
+
+    The clip is zero-padded / cropped to ``length`` inside the kernel."""
+    _lib.init()
+    wave = _req(wave, torch.float32, "wave")
+    if wave.dim() != 2:
+        raise ValueError("wave must be [B, n]")
+    B, n_in = wave.shape
+    T = 1 + length // hop
+    dev = wave.device
+    X = torch.empty((B, NBIN, T, 2), dtype=torch.float32, device=dev) if want_complex else None
+    mag = torch.empty((B, NBIN, T), dtype=torch.float32, device=dev) if want_mag else None
+    ph = torch.empty((B, NBIN, T), dtype=torch.float32, device=dev) if want_phase else None
+    if window is not None:
+        window = _req(window, torch.float32, "window")
+        if window.numel() != win:
+            raise ValueError("window must have `win` elements")
+    rc = _lib.lib().advh_stft_forward(wave.data_ptr(), wave.stride(0), n_in, B, length, hop, win, _ptr(window),
+                                      _ptr(X), _ptr(mag), _ptr(ph), T, _stream())
+    _lib.check(rc, "advh_stft_forward")
+    return (torch.view_as_complex(X) if X is not None else None), mag, ph
+
+
+def istft_masked(mag: torch.Tensor, phase: torch.Tensor, mask: Optional[torch.Tensor], length: int,
+                 domain: str = "log1p", want_in: bool = True, want_out: bool = True, hop: int = 322,
+                 win: int = 644, window: Optional[torch.Tensor] = None
+                 ) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]:
+    """Mask-in / mask-out resynthesis, fused: mask application (``"linear"`` loss_function.py:36-45,
+    ``"log1p"`` LMAC_metrics.py:136-153, ``"none"``) + polar + ISTFT (audioprocessor.py:117-131).
+
+    ``mask [B, Fm, Tm]`` is the U-Net crop; bins outside it count as mask 0."""
+    _lib.init()
+    mag = _req(mag, torch.float32, "mag")
+    phase = _req(phase, torch.float32, "phase")
+    if mag.shape != phase.shape or mag.dim() != 3 or mag.shape[1] != NBIN:
+        raise ValueError("mag / phase must be [B, 513, T]")
+    B, _, T = mag.shape
+    mode = {"none": 0, "linear": 1, "log1p": 2}[domain]
+    Fm = Tm = 0
+    if mode:
+        mask = _req(mask, torch.float32, "mask")
+        if mask.dim() != 3 or mask.shape[0] != B or mask.shape[1] > NBIN or mask.shape[2] > T:
+            raise ValueError("mask must be [B, Fm<=513, Tm<=T]")
+        Fm, Tm = mask.shape[1], mask.shape[2]
+    elif want_out:
+        raise ValueError("domain='none' has no mask-out signal")
+    if T != 1 + length // hop:
+        raise ValueError("T does not match length // hop + 1")
+    w_in = torch.empty((B, length), dtype=torch.float32, device=mag.device) if want_in else None
+    w_out = torch.empty((B, length), dtype=torch.float32, device=mag.device) if want_out else None
+    rc = _lib.lib().advh_istft_masked(mag.data_ptr(), phase.data_ptr(), _ptr(mask) if mode else None, Fm, Tm, mode,
+                                      _ptr(w_in), _ptr(w_out), length, B, T, length, hop, win, _ptr(window), _stream())
+    _lib.check(rc, "advh_istft_masked")
+    return w_in, w_out
+
+
+def istft_complex(spec: torch.Tensor, length: int, hop: int = 322, win: int = 644,
+                  window: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``spec [B,513,T] complex64 -> wave [B, length]`` (audioprocessor.py:117-131)."""
+    _lib.init()
+    if not torch.is_complex(spec):
+        raise ValueError("ISTFT expects complex input!")          # audioprocessor.py:118-119
+    if spec.dtype != torch.complex64 or spec.dim() != 3 or spec.shape[1] != NBIN:
+        raise ValueError("spec must be complex64 [B, 513, T]")
+    sr = torch.view_as_real(spec.contiguous())
+    B, _, T, _ = sr.shape
+    if T != 1 + length // hop:
+        raise ValueError("T does not match length // hop + 1")
+    out = torch.empty((B, length), dtype=torch.float32, device=spec.device)
+    rc = _lib.lib().advh_istft_c64(sr.data_ptr(), out.data_ptr(), length, B, T, length, hop, win, _ptr(window), _stream())
+    _lib.check(rc, "advh_istft_c64")
+    return out

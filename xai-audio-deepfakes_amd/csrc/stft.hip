@@ -1,0 +1,326 @@
+// Framed real FFT (STFT) and masked inverse (ISTFT + overlap-add) for gfx950.
+//
+// Reference arithmetic: AudioProcessor.compute_stft / compute_invert_stft
+// (audioprocessor.py:82-131), mask application loss_function.py:36-45 and LMAC_metrics.py:136-153.
+//
+// Both kernels are HBM-bound (1.89 MB / clip forward, 1.47 MB / clip per
+// resynthesis).  The spectrogram layout is torch's [B][513][T] with t fastest, so a workgroup
+// owns FB = 16 consecutive frames of one clip: every global access of the spectrogram is then a
+// 64-byte (fp32) or 128-byte (complex64) run per frequency bin, and the 16 transforms live in
+// LDS rows (fft512.h) where each of the 4 wavefronts runs whole 512-point transforms in place.
+#include <hip/hip_runtime.h>
+#include <mutex>
+#include "addvisor_hip.h"
+#include "common.h"
+#include "fft512.h"
+
+namespace advh {
+
+__device__ cf g_twiddle[1024];   // e^{+2 pi i k / 1024}
+static bool g_init_done = false;
+
+constexpr int NFFT = 1024;
+constexpr int NBIN = 513;
+constexpr int FB = 16;           // frames per workgroup
+constexpr int THREADS = 256;
+
+__device__ __forceinline__ void wave_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <int DIR>
+__device__ __forceinline__ void fft512_wave(float* re, float* im, int lane) {
+    cf v[8];
+    fft512_pass_load<DIR, 1>(re, im, lane, g_twiddle, v);
+    wave_fence();
+    fft512_pass_store<1>(re, im, lane, v);
+    wave_fence();
+    fft512_pass_load<DIR, 8>(re, im, lane, g_twiddle, v);
+    wave_fence();
+    fft512_pass_store<8>(re, im, lane, v);
+    wave_fence();
+    fft512_pass_load<DIR, 64>(re, im, lane, g_twiddle, v);
+    wave_fence();
+    fft512_pass_store<64>(re, im, lane, v);
+    wave_fence();
+}
+
+// LDS carve: re rows | im rows | scratch (samples for the forward, overlap-add accumulator for the inverse)
+__device__ __forceinline__ void carve(float* smem, float*& re, float*& im, float*& scratch) {
+    re = smem;
+    im = smem + FB * FFT_ROW;
+    scratch = smem + 2 * FB * FFT_ROW;
+}
+
+// ------------------------------------------------------------------------------------------ forward
+__global__ __launch_bounds__(THREADS) void stft_fwd_kernel(
+    const float* __restrict__ wave, long wave_stride, int n_in, int L, int hop, int win,
+    const float* __restrict__ window, float* __restrict__ X, float* __restrict__ mag,
+    float* __restrict__ phase, int T) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *re, *im, *smp;
+    carve(smem, re, im, smp);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int b = blockIdx.y, tA = blockIdx.x * FB;
+    const int left = (NFFT - win) / 2;
+    const int span = (FB - 1) * hop + win;
+
+    // 1. stage the samples the 16 frames touch (reflect padding of the L-sample clip, zero tail)
+    const float* w = wave + (long)b * wave_stride;
+    for (int i = tid; i < span; i += THREADS) {
+        int src = tA * hop + left + i - NFFT / 2;
+        if (src < 0) src = -src;
+        if (src >= L) src = 2 * (L - 1) - src;
+        float v = 0.f;
+        if (src >= 0 && src < n_in && src < L) v = w[src];
+        smp[i] = v;
+    }
+    __syncthreads();
+
+    // 2. one wavefront per frame: build z[n] = x[2n] + i x[2n+1], FFT512, real-transform glue
+    for (int f = wv; f < FB; f += THREADS / 64) {
+        if (tA + f >= T) break;                       // wave-uniform
+        float* rr = re + f * FFT_ROW;
+        float* ii = im + f * FFT_ROW;
+        const float* fs = smp + f * hop;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            int n = lane + 64 * q;
+            int j0 = 2 * n - left, j1 = j0 + 1;
+            float a = 0.f, c = 0.f;
+            if (j0 >= 0 && j0 < win) a = window ? fs[j0] * window[j0] : fs[j0];
+            if (j1 >= 0 && j1 < win) c = window ? fs[j1] * window[j1] : fs[j1];
+            rr[fidx(n)] = a;
+            ii[fidx(n)] = c;
+        }
+        wave_fence();
+        fft512_wave<-1>(rr, ii, lane);
+        cf A[4], Bv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int k = lane + 1 + 64 * q;
+            A[q] = cf{rr[fidx(k)], ii[fidx(k)]};
+            Bv[q] = cf{rr[fidx(512 - k)], ii[fidx(512 - k)]};
+        }
+        cf Z0 = cf{rr[0], ii[0]};
+        wave_fence();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int k = lane + 1 + 64 * q;
+            cf xk, xm;
+            rfft_post_pair(A[q], Bv[q], g_twiddle[k], xk, xm);
+            rr[fidx(k)] = xk.x; ii[fidx(k)] = xk.y;
+            rr[fidx(512 - k)] = xm.x; ii[fidx(512 - k)] = xm.y;
+        }
+        if (lane == 0) {
+            rr[0] = Z0.x + Z0.y; ii[0] = 0.f;
+            rr[fidx(512)] = Z0.x - Z0.y; ii[fidx(512)] = 0.f;
+        }
+    }
+    __syncthreads();
+
+    // 3. coalesced epilogue: t fastest (16 frames = one 64 B / 128 B run per bin)
+    const int nvalid = min(FB, T - tA);
+    for (int idx = tid; idx < NBIN * FB; idx += THREADS) {
+        int tl = idx & (FB - 1), k = idx / FB;
+        if (tl >= nvalid) continue;
+        float xr = re[tl * FFT_ROW + fidx(k)], xi = im[tl * FFT_ROW + fidx(k)];
+        long o = ((long)b * NBIN + k) * T + tA + tl;
+        if (X) reinterpret_cast<float2*>(X)[o] = make_float2(xr, xi);
+        if (mag) mag[o] = hypotf(xr, xi);
+        if (phase) phase[o] = atan2f(xi, xr);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ inverse
+// SRC 0: mag/phase (+ optional mask, mode), SRC 1: complex64 spectrogram
+template <int SRC>
+__global__ __launch_bounds__(THREADS) void istft_kernel(
+    const float* __restrict__ mag, const float* __restrict__ phase, const float* __restrict__ mask,
+    int Fm, int Tm, int mode, int which0, float* __restrict__ out0, float* __restrict__ out1,
+    long wave_stride, int T, int L, int hop, int win, int R, const float* __restrict__ window) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *re, *im, *acc;
+    carve(smem, re, im, acc);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int b = blockIdx.y, g = blockIdx.x;
+    const int which = which0 + blockIdx.z;            // 0: mask-in, 1: mask-out
+    float* out = (blockIdx.z == 0 ? out0 : out1) + (long)b * wave_stride;
+    const int left = (NFFT - win) / 2;
+    const int S = FB - R + 1;                         // complete hop-segments this workgroup emits
+    const int tA = g * S - (R - 1);                   // first frame it transforms (may be < 0)
+    const int nacc = (FB - 1) * hop + win;
+
+    // 1. load the 513 x 16 tile, apply the mask and go polar -> cartesian
+    for (int idx = tid; idx < NBIN * FB; idx += THREADS) {
+        int tl = idx & (FB - 1), k = idx / FB, t = tA + tl;
+        float xr = 0.f, xi = 0.f;
+        if (t >= 0 && t < T) {
+            long o = ((long)b * NBIN + k) * T + t;
+            if (SRC == 1) {
+                float2 v = reinterpret_cast<const float2*>(mag)[o];
+                xr = v.x; xi = v.y;
+            } else {
+                float a = mag[o], ph = phase[o];
+                if (mode != ADVH_MASK_NONE) {
+                    float m = 0.f;
+                    if (k < Fm && t < Tm) m = mask[((long)b * Fm + k) * Tm + t];
+                    if (which == 1) m = 1.f - m;
+                    a = (mode == ADVH_MASK_LINEAR) ? m * a : expm1f(m * log1pf(a));
+                }
+                float s, c;
+                sincosf(ph, &s, &c);
+                xr = a * c; xi = a * s;
+            }
+        }
+        re[tl * FFT_ROW + fidx(k)] = xr;
+        im[tl * FFT_ROW + fidx(k)] = xi;
+    }
+    for (int i = tid; i < nacc; i += THREADS) acc[i] = 0.f;
+    __syncthreads();
+
+    // 2. one wavefront per frame: Hermitian glue, inverse FFT512, windowed overlap-add into LDS
+    for (int f = wv; f < FB; f += THREADS / 64) {
+        int t = tA + f;
+        if (t < 0 || t >= T) continue;                // wave-uniform
+        float* rr = re + f * FFT_ROW;
+        float* ii = im + f * FFT_ROW;
+        cf A[4], Bv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int k = lane + 1 + 64 * q;
+            A[q] = cf{rr[fidx(k)], ii[fidx(k)]};
+            Bv[q] = cf{rr[fidx(512 - k)], ii[fidx(512 - k)]};
+        }
+        float x0 = rr[0], xn = rr[fidx(512)];        // C2R semantics: imaginary parts of DC / Nyquist ignored
+        wave_fence();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int k = lane + 1 + 64 * q;
+            cf zk, zm;
+            irfft_pre_pair(A[q], Bv[q], g_twiddle[k], zk, zm);
+            rr[fidx(k)] = zk.x; ii[fidx(k)] = zk.y;
+            rr[fidx(512 - k)] = zm.x; ii[fidx(512 - k)] = zm.y;
+        }
+        if (lane == 0) { rr[0] = 0.5f * (x0 + xn); ii[0] = 0.5f * (x0 - xn); }
+        wave_fence();
+        fft512_wave<+1>(rr, ii, lane);
+        float* fa = acc + f * hop;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            int n = lane + 64 * q;
+            int j0 = 2 * n - left, j1 = j0 + 1;
+            float a = rr[fidx(n)] * (1.f / 512.f), c = ii[fidx(n)] * (1.f / 512.f);
+            if (j0 >= 0 && j0 < win) atomicAdd(&fa[j0], window ? a * window[j0] : a);
+            if (j1 >= 0 && j1 < win) atomicAdd(&fa[j1], window ? c * window[j1] : c);
+        }
+    }
+    __syncthreads();
+
+    // 3. emit the S complete hop-segments, divided by the window envelope, trimmed to [0, L)
+    const int a0 = (R - 1) * hop;                     // first complete accumulator slot
+    for (int i = tid; i < S * hop; i += THREADS) {
+        int a = a0 + i;
+        int p = tA * hop + left + a;                  // padded-signal coordinate
+        int n = p - NFFT / 2;
+        if (n < 0 || n >= L) continue;
+        // frames covering p:  t*hop + left <= p < t*hop + left + win
+        int thi = (p - left) / hop;
+        float env = 0.f;
+        for (int r = 0; r < R; ++r) {
+            int t = thi - r;
+            int j = p - left - t * hop;
+            if (t >= 0 && t < T && j >= 0 && j < win) { float ww = window ? window[j] : 1.f; env += ww * ww; }
+        }
+        out[n] = env > 1e-11f ? acc[a] / env : 0.f;
+    }
+}
+
+static size_t lds_bytes(int hop, int win) { return sizeof(float) * (2 * FB * FFT_ROW + (FB - 1) * hop + win); }
+
+}  // namespace advh
+
+using namespace advh;
+
+extern "C" const char* advh_version(void) { return "addvisor_hip 0.1 (gfx950, wave64)"; }
+
+extern "C" int advh_init(void) {
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
+    if (g_init_done) return ADVH_OK;
+    cf host[1024];
+    for (int k = 0; k < 1024; ++k) {
+        host[k].x = (float)cos(2.0 * M_PI * k / 1024.0);
+        host[k].y = (float)sin(2.0 * M_PI * k / 1024.0);
+    }
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_twiddle), host, sizeof(host)) != hipSuccess) return ADVH_ELAUNCH;
+    const int maxlds = 160 * 1024;
+    if (hipFuncSetAttribute((const void*)stft_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, maxlds) != hipSuccess) return ADVH_ELAUNCH;
+    if (hipFuncSetAttribute((const void*)istft_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, maxlds) != hipSuccess) return ADVH_ELAUNCH;
+    if (hipFuncSetAttribute((const void*)istft_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, maxlds) != hipSuccess) return ADVH_ELAUNCH;
+    int rc = advh_init_rest();
+    if (rc != ADVH_OK) return rc;
+    g_init_done = true;
+    return ADVH_OK;
+}
+
+static int check_frame_args(int B, int T, int L, int hop, int win) {
+    if (!g_init_done) return ADVH_ENOTINIT;
+    if (B <= 0 || L <= 0 || hop <= 0 || win <= 0 || win > NFFT || (win & 1) || T != 1 + L / hop) return ADVH_EINVAL;
+    if (L <= NFFT / 2) return ADVH_EINVAL;           // reflect padding needs L > n_fft/2
+    if (lds_bytes(hop, win) > 160 * 1024) return ADVH_EUNSUPPORTED;
+    return ADVH_OK;
+}
+
+extern "C" int advh_stft_forward(const float* wave, int64_t wave_stride, int n_in, int B, int L, int hop, int win,
+                                 const float* window, float* X, float* mag, float* phase, int T,
+                                 advh_stream_t stream) {
+    int rc = check_frame_args(B, T, L, hop, win);
+    if (rc) return rc;
+    if (!wave || n_in <= 0 || wave_stride < (n_in < L ? n_in : L)) return ADVH_EINVAL;
+    dim3 grid((T + FB - 1) / FB, B);
+    hipLaunchKernelGGL(stft_fwd_kernel, grid, dim3(THREADS), lds_bytes(hop, win), (hipStream_t)stream, wave,
+                       (long)wave_stride, n_in, L, hop, win, window, X, mag, phase, T);
+    return hipGetLastError() == hipSuccess ? ADVH_OK : ADVH_ELAUNCH;
+}
+
+static int launch_istft(int src, const float* a, const float* ph, const float* mask, int Fm, int Tm, int mode,
+                        float* o0, float* o1, int64_t ws, int B, int T, int L, int hop, int win,
+                        const float* window, advh_stream_t stream) {
+    int rc = check_frame_args(B, T, L, hop, win);
+    if (rc) return rc;
+    const int R = (win + hop - 1) / hop;
+    if (R > FB / 2) return ADVH_EUNSUPPORTED;
+    const int S = FB - R + 1, left = (NFFT - win) / 2;
+    int which0 = 0, nz = 2;
+    float *p0 = o0, *p1 = o1;
+    if (!o0 && !o1) return ADVH_EINVAL;
+    if (!o0) { which0 = 1; p0 = o1; nz = 1; }
+    else if (!o1) { nz = 1; }
+    const int nG = (NFFT / 2 + L - left + S * hop - 1) / (S * hop);
+    dim3 grid(nG, B, nz);
+    if (src == 0)
+        hipLaunchKernelGGL(istft_kernel<0>, grid, dim3(THREADS), lds_bytes(hop, win), (hipStream_t)stream, a, ph, mask,
+                           Fm, Tm, mode, which0, p0, p1, (long)ws, T, L, hop, win, R, window);
+    else
+        hipLaunchKernelGGL(istft_kernel<1>, grid, dim3(THREADS), lds_bytes(hop, win), (hipStream_t)stream, a, ph, mask,
+                           Fm, Tm, mode, which0, p0, p1, (long)ws, T, L, hop, win, R, window);
+    return hipGetLastError() == hipSuccess ? ADVH_OK : ADVH_ELAUNCH;
+}
+
+extern "C" int advh_istft_masked(const float* mag, const float* phase, const float* mask, int Fm, int Tm, int mode,
+                                 float* wave_in, float* wave_out, int64_t wave_stride, int B, int T, int L, int hop,
+                                 int win, const float* window, advh_stream_t stream) {
+    if (!mag || !phase || wave_stride < L) return ADVH_EINVAL;
+    if (mode != ADVH_MASK_NONE && (!mask || Fm <= 0 || Tm <= 0 || Fm > NBIN || Tm > T)) return ADVH_EINVAL;
+    if (mode < 0 || mode > ADVH_MASK_LOG1P) return ADVH_EINVAL;
+    if (mode == ADVH_MASK_NONE && wave_out) return ADVH_EINVAL;
+    return launch_istft(0, mag, phase, mask, Fm, Tm, mode, wave_in, wave_out, wave_stride, B, T, L, hop, win, window, stream);
+}
+
+extern "C" int advh_istft_c64(const float* spec, float* wave, int64_t wave_stride, int B, int T, int L, int hop, int win,
+                              const float* window, advh_stream_t stream) {
+    if (!spec || !wave || wave_stride < L) return ADVH_EINVAL;
+    return launch_istft(1, spec, nullptr, nullptr, 0, 0, ADVH_MASK_NONE, wave, nullptr, wave_stride, B, T, L, hop, win, window, stream);
+}
