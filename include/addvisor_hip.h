@@ -71,6 +71,51 @@ int advh_istft_masked(const float* mag, const float* phase, const float* mask, i
 int advh_istft_c64(const float* spec, float* wave, int64_t wave_stride, int B, int T, int L, int hop, int win,
                    const float* window, advh_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Implicit GEMM on the matrix cores (fp16 operands, fp32 accumulate):
+ *
+ *     out[row(m) + col(n)] = act( sum_k A(m,k) * W[n][k] + bias[n] ) + resid[row(m) + col(n)]
+ *
+ * replaces the cuDNN / cuBLAS calls behind nn.Conv1d, nn.Linear (transformers/models/wav2vec2/
+ * modeling_wav2vec2.py:254-572) and nn.Conv2d / nn.ConvTranspose2d (addvisor.py:12-84).
+ * Activations are channels-last fp16; a convolution tap is a constant offset from the row's base
+ * address, listed per 16-byte K-chunk in `ktab`.
+ *
+ * Row enumeration: m = (b*Hg + h)*Wg + w, 0 <= m < M.  Rows with (h,w) outside the window
+ * [h0,h1) x [w0,w1) are "halo" rows: they read a safe in-window row and, if `halo_zero`, have
+ * zeros written (so a zero-haloed NHWC output map is produced complete by one launch).
+ * A row base, in 16-byte chunks (8 halfs):  b*a_sB[s] + h*a_sH[s] + w*a_sW[s] + a_c0[s]  (source s).
+ * K-chunk c (0 <= c < Ktot/8) reads 8 halfs at  A_s + 8*(rowbase_s + (ktab[c] & 0x7fffffff)),
+ * s = ktab[c] >> 31.  Ktot % 64 == 0; padding chunks must pair zero weights with any readable chunk.
+ * W is [w_rows][Ktot] fp16, w_rows >= N rounded up to the tile's BN (extra rows are read, never used).
+ * Output element offset: b*o_sB + h*o_sH + w*o_sW + o_c0 + (n / n_div)*o_sNhi + n % n_div + z*o_sZ
+ * (n_div % 4 == 0; every term a multiple of 4 elements).  `nz` batches (grid z) advance the
+ * operands by a_sZ (chunks), w_sZ (elements), bias_sZ, o_sZ.                                     */
+enum { ADVH_ACT_NONE = 0, ADVH_ACT_GELU = 1, ADVH_ACT_LEAKY = 2 };
+enum { ADVH_TILE_AUTO = 0, ADVH_TILE_128x128 = 1, ADVH_TILE_256x64 = 2, ADVH_TILE_256x32 = 3 };
+
+typedef struct advh_gemm_desc {
+    const void* A0;       /* fp16 source 0                                   */
+    const void* A1;       /* fp16 source 1 (skip-concat by pointer) or NULL  */
+    const void* W;        /* fp16 [nz][w_rows][Ktot]                         */
+    const int32_t* ktab;  /* [Ktot/8] chunk offsets, bit 31 selects A1       */
+    const float* bias;    /* fp32 [nz][N] or NULL                            */
+    const void* resid;    /* residual, addressed like out, or NULL           */
+    void* out_h;          /* fp16 output or NULL                             */
+    void* out_f;          /* fp32 output or NULL                             */
+    int32_t M, N, Ktot, w_rows;
+    int32_t Hg, Wg, h0, h1, w0, w1, halo_zero;
+    int64_t a_sB[2], a_sH[2], a_sW[2], a_c0[2], a_sZ[2];
+    int64_t w_sZ, bias_sZ;
+    int64_t o_sB, o_sH, o_sW, o_c0, o_sNhi, o_sZ;
+    int32_t n_div, nz;
+    int32_t act;          /* ADVH_ACT_*                                      */
+    float slope;          /* LeakyReLU slope                                 */
+    int32_t resid_f32;    /* 1: resid is fp32, 0: fp16                       */
+} advh_gemm_desc;
+
+int advh_gemm_f16(const advh_gemm_desc* desc, int tile, advh_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,89 @@
+"""CPU-only host-logic tests: every implicit-GEMM plan (K-chunk tables, strides, halo windows) is
+replayed in numpy with the kernel's own addressing rule and compared with torch's convolutions."""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from addvisor_hip import gemm as G
+
+torch.manual_seed(0)
+
+
+def rnd(*shape):
+    return torch.randn(*shape)
+
+
+def fill(f: G.FMap, x_nchw: torch.Tensor):
+    f.t = torch.zeros((f.B, f.Hp, f.Wp, f.C), dtype=torch.float16)
+    f.interior()[:] = x_nchw.permute(0, 2, 3, 1).to(torch.float16)
+    return f
+
+
+def test_linear_plan():
+    M, K, N = 37, 64, 48
+    a, w, b = rnd(M, K).half(), rnd(N, K), rnd(N)
+    p = G.plan_linear(M, w, b, act="gelu")
+    out = G.replay_on_cpu(p, a, None, M * N).view(M, N)
+    ref = F.gelu(a.float() @ w.half().float().T + b)
+    assert torch.allclose(out, ref, atol=1e-4)
+
+
+def test_conv1d_channels_last_plan():
+    B, Cin, Cout, k, s = 2, 16, 24, 3, 2
+    L_in, L_out = 21, 10
+    P_out, P_in = 12, 24
+    x = rnd(B, Cin, L_in)
+    w, b = rnd(Cout, Cin, k), rnd(Cout)
+    xin = torch.zeros(B, P_in, Cin, dtype=torch.float16)
+    xin[:, :L_in] = x.transpose(1, 2).half()
+    ref = F.gelu(F.conv1d(xin[:, :L_in].float().transpose(1, 2), w.half().float(), b, stride=s))
+    p = G.plan_conv1d_cl(B, P_in, P_out, L_out, w, b, s)
+    out = G.replay_on_cpu(p, xin, None, B * P_out * Cout).view(B, P_out, Cout)
+    assert torch.allclose(out[:, :L_out], ref.transpose(1, 2), atol=1e-4)
+    assert (out[:, L_out:] == 0).all()                      # filler rows are written as zeros
+    pc = G.plan_conv1d_cl(B, P_in, P_out, L_out, w, b, s, compact_out=True)
+    outc = G.replay_on_cpu(pc, xin, None, B * L_out * Cout).view(B, L_out, Cout)
+    assert torch.allclose(outc, ref.transpose(1, 2), atol=1e-4)
+
+
+def conv_case(Cins, Cout, k, stride, pad, dil, H, W, halo_in, halo_out, B=2):
+    xs = [rnd(B, c, H, W) for c in Cins]
+    w, b = rnd(Cout, sum(Cins), *k) * 0.2, rnd(Cout)
+    srcs = [fill(G.FMap(B, H, W, c, *halo_in), x) for c, x in zip(Cins, xs)]
+    ref = F.leaky_relu(F.conv2d(torch.cat([x.half().float() for x in xs], 1), w.half().float(), b, stride=stride,
+                                padding=pad, dilation=dil), 0.2)
+    Ho, Wo = ref.shape[2:]
+    dst = G.FMap(B, Ho, Wo, Cout, *halo_out)
+    p = G.plan_conv2d(srcs, dst, w, b, stride=stride, padding=pad, dilation=dil)
+    out = G.replay_on_cpu(p, srcs[0].t, srcs[1].t if len(srcs) > 1 else None, B * dst.Hp * dst.Wp * Cout)
+    out = out.view(B, dst.Hp, dst.Wp, Cout)
+    inner = out[:, dst.PH:dst.PH + Ho, dst.PW:dst.PW + Wo].permute(0, 3, 1, 2)
+    assert torch.allclose(inner, ref, atol=2e-3), (inner - ref).abs().max()
+    halo = out.clone()
+    halo[:, dst.PH:dst.PH + Ho, dst.PW:dst.PW + Wo] = 0
+    assert not torch.isnan(out).any() and (halo == 0).all()   # the whole padded map is produced, halo = 0
+
+
+def test_conv2d_plans():
+    conv_case([8], 8, (3, 3), (1, 1), (1, 1), (1, 1), 6, 5, (1, 1), (1, 1))
+    conv_case([8], 16, (5, 3), (2, 1), (2, 1), (1, 1), 8, 5, (2, 1), (1, 1))       # e1/e2-style stride (2,1)
+    conv_case([16], 8, (3, 3), (2, 2), (1, 1), (1, 1), 8, 6, (1, 1), (2, 2))       # e3/e4-style stride 2
+    conv_case([8], 8, (3, 3), (1, 1), (2, 2), (2, 2), 6, 7, (2, 2), (4, 4))        # dilated bottleneck
+    conv_case([8], 8, (3, 3), (1, 1), (4, 4), (4, 4), 6, 7, (4, 4), (0, 0))
+    conv_case([16, 8], 8, (3, 3), (1, 1), (1, 1), (1, 1), 4, 6, (1, 1), (1, 1))    # skip-concat by pointer
+    conv_case([8], 8, (3, 3), (1, 1), (1, 1), (1, 1), 4, 4, (2, 3), (1, 1))        # halo wider than needed
+
+
+def test_convT2d_plan():
+    for stride in ((2, 2), (2, 1)):
+        B, Cin, Cout, H, W = 2, 16, 8, 3, 4
+        x, w, b = rnd(B, Cin, H, W), rnd(Cin, Cout, *stride) * 0.3, rnd(Cout)
+        src = fill(G.FMap(B, H, W, Cin, 1, 2), x)
+        ref = F.conv_transpose2d(x.half().float(), w.half().float(), b, stride=stride)
+        dst = G.FMap(B, H * stride[0], W * stride[1], Cout + 8, 1, 1)               # written at channel offset 4
+        p = G.plan_convT2d(src, dst, w, b, stride=stride, dst_c0=4)
+        out = G.replay_on_cpu(p, src.t, None, B * dst.Hp * dst.Wp * dst.C).view(B, dst.Hp, dst.Wp, dst.C)
+        inner = out[:, 1:1 + dst.H, 1:1 + dst.W, 4:4 + Cout].permute(0, 3, 1, 2)
+        assert torch.allclose(inner, ref, atol=2e-3)
+        out[:, 1:1 + dst.H, 1:1 + dst.W, 4:4 + Cout] = float("nan")
+        assert torch.isnan(out).all()                          # nothing else is touched

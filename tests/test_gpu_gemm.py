@@ -1,0 +1,118 @@
+"""GPU parity of the implicit-GEMM kernel (csrc/gemm.hip) against torch CPU convolutions / matmuls
+evaluated on the same fp16-rounded operands (fp32 math).  Stated tolerance: outputs are fp16, so
+|err| <= 2e-3 * max|ref| + 2e-3 (fp16 has 11 significand bits; accumulation is fp32)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from addvisor_hip import gemm as G, _lib
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+
+
+def rnd(gen, *shape):
+    return torch.randn(*shape, generator=gen)
+
+
+def close(out, ref, tol=2e-3):
+    out, ref = out.float().cpu(), ref.float()
+    err = (out - ref).abs().max().item()
+    assert err <= tol * ref.abs().max().item() + tol, (err, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("M,K,N,act", [(300, 768, 2304, "none"), (12736, 768, 768, "gelu"), (1000, 3072, 768, "none"),
+                                      (257, 512, 64, "gelu"), (513, 64, 32, "leaky"), (128, 64, 48, "none")])
+def test_linear(gpu_device, M, K, N, act):
+    _lib.init()
+    g = torch.Generator().manual_seed(M + N)
+    a, w, b = rnd(g, M, K).half(), rnd(g, N, K) / K ** 0.5, rnd(g, N)
+    res = rnd(g, M, N)
+    p = G.plan_linear(M, w, b, act=act, device=gpu_device)
+    pad = torch.zeros(1024, K, dtype=torch.float16)             # slack rows: tail tiles read a safe row, never OOB
+    A = torch.cat([a, pad]).to(gpu_device)
+    out_h = torch.zeros(M, N, dtype=torch.float16, device=gpu_device)
+    out_f = torch.zeros(M, N, dtype=torch.float32, device=gpu_device)
+    p.run(A, out_h=out_h, out_f=out_f, resid=res.to(gpu_device))
+    y = a.float() @ w.half().float().T + b
+    y = F.gelu(y) if act == "gelu" else (F.leaky_relu(y, 0.0) if act == "leaky" else y)
+    close(out_f, y + res, 2e-4)
+    close(out_h, y + res)
+
+
+def test_conv1d_feature_encoder_shape(gpu_device):
+    """Layer-1 shape of the wav2vec2 feature encoder (k=3, s=2, 512->512) on a short clip."""
+    _lib.init()
+    g = torch.Generator().manual_seed(1)
+    B, C, L_in = 3, 512, 1599
+    L_out = (L_in - 3) // 2 + 1
+    P_out = L_out + 1
+    P_in = 2 * P_out
+    x, w = rnd(g, B, C, L_in), rnd(g, C, C, 3) / (3 * C) ** 0.5
+    xin = torch.zeros(B, P_in, C, dtype=torch.float16)
+    xin[:, :L_in] = x.transpose(1, 2).half()
+    ref = F.gelu(F.conv1d(xin[:, :L_in].float().transpose(1, 2), w.half().float(), None, stride=2)).transpose(1, 2)
+    p = G.plan_conv1d_cl(B, P_in, P_out, L_out, w, None, 2, device=gpu_device)
+    out = torch.full((B, P_out, C), 7.0, dtype=torch.float16, device=gpu_device)
+    p.run(xin.to(gpu_device), out_h=out)
+    close(out[:, :L_out], ref)
+    assert (out[:, L_out:] == 0).all()
+    pc = G.plan_conv1d_cl(B, P_in, P_out, L_out, w, None, 2, compact_out=True, device=gpu_device)
+    outc = torch.zeros((B, L_out, C), dtype=torch.float16, device=gpu_device)
+    pc.run(xin.to(gpu_device), out_h=outc)
+    close(outc, ref)
+
+
+CASES = [
+    # Cins, Cout, k, stride, pad, dil, H, W, halo_in, halo_out
+    ([32], 32, (3, 3), (1, 1), (1, 1), (1, 1), 40, 28, (1, 1), (1, 1)),
+    ([32], 64, (5, 3), (2, 1), (2, 1), (1, 1), 64, 20, (2, 1), (1, 1)),
+    ([64], 128, (3, 3), (2, 2), (1, 1), (1, 1), 32, 28, (1, 1), (1, 1)),
+    ([256], 512, (3, 3), (1, 1), (2, 2), (2, 2), 16, 13, (2, 2), (4, 4)),
+    ([512], 512, (3, 3), (1, 1), (4, 4), (4, 4), 8, 13, (4, 4), (0, 0)),
+    ([256, 128], 256, (3, 3), (1, 1), (1, 1), (1, 1), 16, 12, (1, 1), (1, 1)),
+    ([64, 32], 64, (3, 3), (1, 1), (1, 1), (1, 1), 24, 20, (1, 1), (1, 1)),
+    ([32, 8], 32, (3, 3), (1, 1), (1, 1), (1, 1), 24, 20, (1, 1), (0, 0)),
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_conv2d(gpu_device, case):
+    _lib.init()
+    Cins, Cout, k, stride, pad, dil, H, W, halo_in, halo_out = case
+    B = 3
+    g = torch.Generator().manual_seed(Cout + H)
+    xs = [rnd(g, B, c, H, W) for c in Cins]
+    w, b = rnd(g, Cout, sum(Cins), *k) / (sum(Cins) * k[0] * k[1]) ** 0.5, rnd(g, Cout)
+    srcs = []
+    for c, x in zip(Cins, xs):
+        f = G.FMap(B, H, W, c, *halo_in).alloc(gpu_device)
+        f.interior()[:] = x.permute(0, 2, 3, 1).half().to(gpu_device)
+        srcs.append(f)
+    ref = F.leaky_relu(F.conv2d(torch.cat([x.half().float() for x in xs], 1), w.half().float(), b, stride=stride,
+                                padding=pad, dilation=dil), 0.2)
+    dst = G.FMap(B, ref.shape[2], ref.shape[3], Cout, *halo_out).alloc(gpu_device)
+    dst.t.fill_(5.0)
+    p = G.plan_conv2d(srcs, dst, w, b, stride=stride, padding=pad, dilation=dil, device=gpu_device)
+    p.run(srcs[0].t, srcs[1].t if len(srcs) > 1 else None, out_h=dst.t)
+    close(dst.interior().permute(0, 3, 1, 2), ref)
+    t = dst.t.clone()
+    t[:, dst.PH:dst.PH + dst.H, dst.PW:dst.PW + dst.W] = 0
+    assert (t == 0).all()
+
+
+@pytest.mark.parametrize("stride,Cin,Cout", [((2, 2), 512, 256), ((2, 1), 64, 32)])
+def test_convT2d(gpu_device, stride, Cin, Cout):
+    _lib.init()
+    g = torch.Generator().manual_seed(Cin)
+    B, H, W = 2, 9, 11
+    x, w, b = rnd(g, B, Cin, H, W), rnd(g, Cin, Cout, *stride) / Cin ** 0.5, rnd(g, Cout)
+    src = G.FMap(B, H, W, Cin, 2, 1).alloc(gpu_device)
+    src.interior()[:] = x.permute(0, 2, 3, 1).half().to(gpu_device)
+    dst = G.FMap(B, H * stride[0], W * stride[1], Cout + 8, 1, 1).alloc(gpu_device)
+    p = G.plan_convT2d(src, dst, w, b, stride=stride, dst_c0=8, device=gpu_device)
+    p.run(src.t, out_h=dst.t)
+    ref = F.conv_transpose2d(x.half().float(), w.half().float(), b, stride=stride)
+    close(dst.interior()[..., 8:].permute(0, 3, 1, 2), ref)
+    assert (dst.interior()[..., :8] == 0).all()

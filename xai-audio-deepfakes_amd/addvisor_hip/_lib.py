@@ -40,6 +40,7 @@ SIGNATURES = {
     "advh_stft_forward": (_i, [_p, _i64, _i, _i, _i, _i, _i, _p, _p, _p, _p, _i, _p]),
     "advh_istft_masked": (_i, [_p, _p, _p, _i, _i, _i, _p, _p, _i64, _i, _i, _i, _i, _i, _p, _p]),
     "advh_istft_c64": (_i, [_p, _p, _i64, _i, _i, _i, _i, _i, _p, _p]),
+    "advh_gemm_f16": (_i, [_p, _i, _p]),
 }
 
 _lib = None

@@ -1,0 +1,291 @@
+"""Host-side planning for the implicit-GEMM kernel (``advh_gemm_f16``, include/addvisor_hip.h).
+
+A *plan* is the filled ``advh_gemm_desc`` plus the device tensors it points to (packed fp16 weights,
+fp32 bias, the K-chunk offset table).  Plans are built once per (layer, batch size) and replayed.
+All index arithmetic that decides which addresses a kernel touches lives here and is unit-tested on
+the CPU (tests/test_gemm_plan.py) by replaying the descriptor in numpy.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+
+BK = 64
+ACT = {"none": 0, "gelu": 1, "leaky": 2}
+TILE_AUTO, TILE_128x128, TILE_256x64, TILE_256x32 = 0, 1, 2, 3
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [
+        ("A0", C.c_void_p), ("A1", C.c_void_p), ("W", C.c_void_p), ("ktab", C.c_void_p),
+        ("bias", C.c_void_p), ("resid", C.c_void_p), ("out_h", C.c_void_p), ("out_f", C.c_void_p),
+        ("M", C.c_int32), ("N", C.c_int32), ("Ktot", C.c_int32), ("w_rows", C.c_int32),
+        ("Hg", C.c_int32), ("Wg", C.c_int32), ("h0", C.c_int32), ("h1", C.c_int32),
+        ("w0", C.c_int32), ("w1", C.c_int32), ("halo_zero", C.c_int32),
+        ("a_sB", C.c_int64 * 2), ("a_sH", C.c_int64 * 2), ("a_sW", C.c_int64 * 2),
+        ("a_c0", C.c_int64 * 2), ("a_sZ", C.c_int64 * 2),
+        ("w_sZ", C.c_int64), ("bias_sZ", C.c_int64),
+        ("o_sB", C.c_int64), ("o_sH", C.c_int64), ("o_sW", C.c_int64), ("o_c0", C.c_int64),
+        ("o_sNhi", C.c_int64), ("o_sZ", C.c_int64),
+        ("n_div", C.c_int32), ("nz", C.c_int32), ("act", C.c_int32), ("slope", C.c_float),
+        ("resid_f32", C.c_int32),
+    ]
+
+
+def round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+def pick_tile(N: int) -> Tuple[int, int]:
+    """(tile id, BN) the AUTO rule of advh_gemm_f16 picks."""
+    if N > 64:
+        return TILE_128x128, 128
+    if N > 32:
+        return TILE_256x64, 64
+    return TILE_256x32, 32
+
+
+@dataclass
+class Source:
+    """Addressing of one A source, in 16-byte chunks (8 halfs)."""
+    sB: int
+    sH: int
+    sW: int
+    c0: int
+    sZ: int = 0
+
+
+class GemmPlan:
+    """One launch of the implicit GEMM.  ``ktab_host``/``desc`` stay inspectable for the CPU tests."""
+
+    def __init__(self, *, M: int, N: int, w2: torch.Tensor, ktab: np.ndarray, sources: Sequence[Source],
+                 Hg: int, Wg: int, window: Tuple[int, int, int, int], halo_zero: bool,
+                 out: Tuple[int, int, int, int], n_div: Optional[int] = None, o_sNhi: int = 0,
+                 o_sZ: int = 0, nz: int = 1, bias: Optional[torch.Tensor] = None, act: str = "none",
+                 slope: float = 0.0, device=None, w_sZ: Optional[int] = None, bias_sZ: int = 0):
+        """``w2``: fp32 ``[nz, N, K]`` (K = 8 * len(ktab) before padding); ``ktab``: int64 chunk offsets with
+        bit 31 as source selector; ``out`` = (o_sB, o_sH, o_sW, o_c0) in elements."""
+        assert w2.dim() == 3 and w2.shape[0] == nz and w2.shape[1] == N
+        K = w2.shape[2]
+        assert K == 8 * len(ktab), (K, len(ktab))
+        Kp = round_up(K, BK)
+        tile, BN = pick_tile(N)
+        w_rows = round_up(N, BN)
+        wp = torch.zeros((nz, w_rows, Kp), dtype=torch.float16)
+        wp[:, :N, :K] = w2.to(torch.float16)
+        kt = np.concatenate([ktab, np.full((Kp - K) // 8, ktab[0], dtype=np.int64)]).astype(np.int64)
+        assert (kt & 0x7FFFFFFF).max() < 2 ** 31
+        self.ktab_host = kt
+        self.K, self.Kp, self.tile, self.BN = K, Kp, tile, BN
+        self.device = device
+        self.w = wp.to(device) if device is not None else wp
+        kt32 = torch.from_numpy(kt.astype(np.uint32).view(np.int32).copy())
+        self.ktab = kt32.to(device) if device is not None else kt32
+        self.bias = None
+        if bias is not None:
+            assert bias.numel() == nz * N or bias_sZ == 0
+            b = bias.to(torch.float32).contiguous()
+            self.bias = b.to(device) if device is not None else b
+        d = GemmDesc()
+        d.M, d.N, d.Ktot, d.w_rows = M, N, Kp, w_rows
+        d.Hg, d.Wg = Hg, Wg
+        d.h0, d.h1, d.w0, d.w1 = window
+        d.halo_zero = int(halo_zero)
+        for s, src in enumerate(sources):
+            d.a_sB[s], d.a_sH[s], d.a_sW[s], d.a_c0[s], d.a_sZ[s] = src.sB, src.sH, src.sW, src.c0, src.sZ
+        d.w_sZ = w_rows * Kp if w_sZ is None else w_sZ
+        d.bias_sZ = bias_sZ
+        d.o_sB, d.o_sH, d.o_sW, d.o_c0 = out
+        d.o_sNhi, d.o_sZ = o_sNhi, o_sZ
+        d.n_div = n_div if n_div is not None else round_up(N, 4)
+        d.nz = nz
+        d.act, d.slope = ACT[act], slope
+        self.desc = d
+        self.nsrc = len(sources)
+        self.flops = 2.0 * M * N * K * nz          # algorithmic (unpadded) FLOPs of this launch
+
+    def run(self, A0: torch.Tensor, A1: Optional[torch.Tensor] = None, *, out_h: Optional[torch.Tensor] = None,
+            out_f: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None, stream: Optional[int] = None):
+        d = self.desc
+        assert A0.dtype == torch.float16 and A0.is_cuda
+        d.A0 = A0.data_ptr()
+        d.A1 = A1.data_ptr() if A1 is not None else None
+        assert (A1 is not None) == (self.nsrc == 2)
+        d.W, d.ktab = self.w.data_ptr(), self.ktab.data_ptr()
+        d.bias = self.bias.data_ptr() if self.bias is not None else None
+        d.out_h = out_h.data_ptr() if out_h is not None else None
+        d.out_f = out_f.data_ptr() if out_f is not None else None
+        if out_h is not None:
+            assert out_h.dtype == torch.float16
+        if out_f is not None:
+            assert out_f.dtype == torch.float32
+        if resid is not None:
+            assert resid.dtype in (torch.float16, torch.float32)
+            d.resid, d.resid_f32 = resid.data_ptr(), int(resid.dtype == torch.float32)
+        else:
+            d.resid, d.resid_f32 = None, 0
+        if stream is None:
+            stream = torch.cuda.current_stream().cuda_stream
+        _lib.check(_lib.lib().advh_gemm_f16(C.byref(d), self.tile, stream), "advh_gemm_f16")
+
+
+# ------------------------------------------------------------------------------------------ layouts
+@dataclass
+class FMap:
+    """Zero-haloed NHWC fp16 feature map ``[B, H+2PH, W+2PW, C]`` (C % 8 == 0)."""
+    B: int
+    H: int
+    W: int
+    C: int
+    PH: int
+    PW: int
+    t: Optional[torch.Tensor] = None
+
+    @property
+    def Hp(self):
+        return self.H + 2 * self.PH
+
+    @property
+    def Wp(self):
+        return self.W + 2 * self.PW
+
+    def alloc(self, device):
+        self.t = torch.zeros((self.B, self.Hp, self.Wp, self.C), dtype=torch.float16, device=device)
+        return self
+
+    def interior(self) -> torch.Tensor:
+        return self.t[:, self.PH:self.PH + self.H, self.PW:self.PW + self.W, :]
+
+
+def plan_linear(M: int, weight: torch.Tensor, bias: Optional[torch.Tensor], *, lda: Optional[int] = None,
+                ldo: Optional[int] = None, o_c0: int = 0, act: str = "none", device=None) -> GemmPlan:
+    """``out[m, :N] = act(A[m, :K] @ weight.T + bias)``; nn.Linear (modeling_wav2vec2.py:422-572)."""
+    N, K = weight.shape
+    assert K % 8 == 0
+    lda = K if lda is None else lda
+    ldo = N if ldo is None else ldo
+    assert lda % 8 == 0 and ldo % 4 == 0
+    return GemmPlan(M=M, N=N, w2=weight[None].float(), ktab=np.arange(K // 8, dtype=np.int64),
+                    sources=[Source(0, 0, lda // 8, 0)], Hg=1, Wg=M, window=(0, 1, 0, M), halo_zero=False,
+                    out=(0, 0, ldo, o_c0), bias=bias, act=act, device=device)
+
+
+def plan_conv1d_cl(B: int, P_in: int, P_out: int, L_out: int, weight: torch.Tensor, bias: Optional[torch.Tensor],
+                   stride: int, *, act: str = "gelu", compact_out: bool = False, device=None) -> GemmPlan:
+    """Channels-last Conv1d (no padding) as an overlapping-row GEMM: wav2vec2 feature-encoder layers 1-6
+    (modeling_wav2vec2.py:254-323).  Input ``[B, P_in, Cin]``, rows >= L_in are zero filler; output
+    ``[B, P_out, Cout]`` with rows >= L_out written as zeros, or ``[B, L_out, Cout]`` if ``compact_out``."""
+    Cout, Cin, k = weight.shape
+    assert Cin % 8 == 0
+    w2 = weight.permute(0, 2, 1).reshape(1, Cout, k * Cin).float()          # K order: (tap, channel)
+    out = (L_out * Cout, 0, Cout, 0) if compact_out else (P_out * Cout, 0, Cout, 0)
+    return GemmPlan(M=B * P_out, N=Cout, w2=w2, ktab=np.arange(k * Cin // 8, dtype=np.int64),
+                    sources=[Source(P_in * Cin // 8, 0, stride * Cin // 8, 0)], Hg=1, Wg=P_out,
+                    window=(0, 1, 0, L_out), halo_zero=not compact_out, out=out, bias=bias, act=act, device=device)
+
+
+def plan_conv2d(srcs: Sequence[FMap], dst: FMap, weight: torch.Tensor, bias: Optional[torch.Tensor], *,
+                stride=(1, 1), padding=(1, 1), dilation=(1, 1), act: str = "leaky", slope: float = 0.2,
+                dst_c0: int = 0, device=None) -> GemmPlan:
+    """nn.Conv2d on zero-haloed NHWC maps (addvisor.py:12-60); ``srcs`` are concatenated along channels
+    by pointer (torch.cat of addvisor.py:70-80).  Enumerates the padded OUTPUT grid and writes its halo
+    as zeros, so ``dst`` is complete after one launch."""
+    Cout, Cin, KH, KW = weight.shape
+    assert sum(s.C for s in srcs) == Cin and len(srcs) <= 2
+    sh, sw = stride
+    ph, pw = padding
+    dh, dw = dilation
+    B = dst.B
+    Ho = (srcs[0].H + 2 * ph - dh * (KH - 1) - 1) // sh + 1
+    Wo = (srcs[0].W + 2 * pw - dw * (KW - 1) - 1) // sw + 1
+    assert (Ho, Wo) == (dst.H, dst.W), ((Ho, Wo), (dst.H, dst.W))
+    ktabs, ws, sources = [], [], []
+    c_lo = 0
+    for s, f in enumerate(srcs):
+        assert f.C % 8 == 0 and f.PH >= ph and f.PW >= pw and (f.H, f.W, f.B) == (srcs[0].H, srcs[0].W, B)
+        cc = f.C // 8
+        taps = (np.arange(KH)[:, None] * dh * f.Wp + np.arange(KW)[None, :] * dw).reshape(-1)   # positions
+        kt = (taps[:, None] * cc + np.arange(cc)[None, :]).reshape(-1).astype(np.int64) | (s << 31)
+        ktabs.append(kt)
+        ws.append(weight[:, c_lo:c_lo + f.C].permute(0, 2, 3, 1).reshape(Cout, KH * KW * f.C))
+        c0 = ((-sh * dst.PH + f.PH - ph) * f.Wp + (-sw * dst.PW + f.PW - pw)) * cc
+        sources.append(Source(f.Hp * f.Wp * cc, sh * f.Wp * cc, sw * cc, c0))
+        c_lo += f.C
+    Ct = dst.C
+    return GemmPlan(M=B * dst.Hp * dst.Wp, N=Cout, w2=torch.cat(ws, 1)[None].float(), ktab=np.concatenate(ktabs),
+                    sources=sources, Hg=dst.Hp, Wg=dst.Wp,
+                    window=(dst.PH, dst.PH + dst.H, dst.PW, dst.PW + dst.W), halo_zero=True,
+                    out=(dst.Hp * dst.Wp * Ct, dst.Wp * Ct, Ct, dst_c0), bias=bias, act=act, slope=slope,
+                    device=device)
+
+
+def plan_convT2d(src: FMap, dst: FMap, weight: torch.Tensor, bias: torch.Tensor, *, stride, dst_c0: int = 0,
+                 device=None) -> GemmPlan:
+    """nn.ConvTranspose2d with kernel == stride (addvisor.py:45-54): a GEMM over the input pixels whose
+    epilogue scatters the (i, j) sub-pixels (grid z = i, column block = j).  Only ``dst``'s interior is
+    written; its halo must already be zero."""
+    Cin, Cout, KH, KW = weight.shape
+    sh, sw = stride
+    assert (KH, KW) == (sh, sw) and src.C == Cin and Cin % 8 == 0 and Cout % 4 == 0
+    assert (dst.H, dst.W) == (src.H * sh, src.W * sw)
+    cc = Cin // 8
+    Ct = dst.C
+    # w2[z=i][n = j*Cout + co][ci]
+    w2 = weight.permute(2, 3, 1, 0).reshape(sh, sw * Cout, Cin).float()
+    b2 = bias.float().repeat(sw)
+    o_c0 = ((-sh * src.PH + dst.PH) * dst.Wp + (-sw * src.PW + dst.PW)) * Ct + dst_c0
+    return GemmPlan(M=src.B * src.Hp * src.Wp, N=sw * Cout, w2=w2, ktab=np.arange(cc, dtype=np.int64),
+                    sources=[Source(src.Hp * src.Wp * cc, src.Wp * cc, cc, 0)], Hg=src.Hp, Wg=src.Wp,
+                    window=(src.PH, src.PH + src.H, src.PW, src.PW + src.W), halo_zero=False,
+                    out=(dst.Hp * dst.Wp * Ct, sh * dst.Wp * Ct, sw * Ct, o_c0), n_div=Cout, o_sNhi=Ct,
+                    o_sZ=dst.Wp * Ct, nz=sh, bias=b2, bias_sZ=0, act="none", device=device)
+
+
+# ------------------------------------------------------------------------------------------ CPU replay
+def replay_on_cpu(plan: GemmPlan, A0: torch.Tensor, A1: Optional[torch.Tensor], out_numel: int,
+                  resid: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Execute a plan's descriptor in numpy exactly as the kernel addresses memory (fp32 math).
+    Host-logic test aid: checks ktab / strides / windows without a GPU.  Small shapes only."""
+    d = plan.desc
+    srcs = [A0.reshape(-1).float().numpy(), None if A1 is None else A1.reshape(-1).float().numpy()]
+    W = plan.w.float().numpy()
+    bias = None if plan.bias is None else plan.bias.numpy().reshape(-1)
+    out = np.full(out_numel, np.nan, dtype=np.float32)
+    kt = plan.ktab_host
+    sel, off = (kt >> 31).astype(np.int64), (kt & 0x7FFFFFFF).astype(np.int64)
+    for z in range(d.nz):
+        for m in range(d.M):
+            w_, t_ = m % d.Wg, m // d.Wg
+            h_, b_ = t_ % d.Hg, t_ // d.Hg
+            ok = d.h0 <= h_ < d.h1 and d.w0 <= w_ < d.w1
+            if not ok and not d.halo_zero:
+                continue
+            orow = b_ * d.o_sB + h_ * d.o_sH + w_ * d.o_sW + d.o_c0 + d.o_sZ * z
+            cols = np.arange(d.N)
+            o = orow + (cols // d.n_div) * d.o_sNhi + cols % d.n_div
+            if not ok:
+                out[o] = 0.0
+                continue
+            row = np.empty(d.Ktot, dtype=np.float32)
+            for c in range(d.Ktot // 8):
+                s = sel[c]
+                rb = b_ * d.a_sB[s] + h_ * d.a_sH[s] + w_ * d.a_sW[s] + d.a_c0[s] + d.a_sZ[s] * z
+                a = (rb + off[c]) * 8
+                row[c * 8:(c + 1) * 8] = srcs[s][a:a + 8]
+            v = W[z, :d.N] @ row
+            if bias is not None:
+                v = v + bias[d.bias_sZ * z: d.bias_sZ * z + d.N]
+            if d.act == 1:
+                v = torch.nn.functional.gelu(torch.from_numpy(v)).numpy()
+            elif d.act == 2:
+                v = np.where(v > 0, v, d.slope * v)
+            if resid is not None:
+                v = v + resid.reshape(-1).float().numpy()[o]
+            out[o] = v
+    return torch.from_numpy(out)

@@ -1,0 +1,217 @@
+// Implicit-GEMM on the gfx950 matrix cores: fp16 operands, fp32 accumulate.
+//
+//     out[row(m), col(n)] = act( sum_k A(m, k) * W[n][k] + bias[n] ) + resid[row(m), col(n)]
+//
+// One kernel serves every dense contraction of the hot path:
+//   * wav2vec2 feature-encoder Conv1d layers 1-6 (transformers/.../modeling_wav2vec2.py:254-323):
+//     channels-last activations make the im2col row of output t the CONTIGUOUS slab
+//     x[s*t : s*t+k, :], so the conv is a GEMM whose A rows overlap (row stride s*C, K = k*C);
+//   * the grouped positional Conv1d (k=128, 16 groups; :326-379) the same way, batched over groups;
+//   * every Linear of the encoder (:438-572) and the feature projection (:422-434);
+//   * the U-Net's Conv2d / dilated Conv2d / ConvTranspose2d (addvisor.py:12-84) on zero-haloed
+//     NHWC maps: a tap is a constant offset from the row's base address, so K walks a table of
+//     16-byte chunk offsets (`ktab`), optionally over two sources (skip-concat by pointer).
+//
+// Structure (cdna_hip_programming.md §5): 256 threads = 4 wavefronts, BMxBNx64 tile, both
+// operands staged global->LDS with 16-byte `global_load_lds` (per-lane source address, linear LDS
+// image, XOR swizzle applied on the SOURCE side and on the ds_read side), v_mfma_f32_16x16x32_f16,
+// several resident workgroups per CU for overlap.  W is the MFMA A operand and the activations the
+// B operand, so a lane's 4 accumulator registers are 4 CONSECUTIVE output channels of one row:
+// the epilogue stores 8 B (fp16) / 16 B (fp32) per lane without any shuffle.
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include "addvisor_hip.h"
+#include "common.h"
+
+namespace advh {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+constexpr int BK = 64;          // halfs per K-step = 8 chunks of 16 B
+
+__device__ __forceinline__ float apply_act(float x, int act, float slope) {
+    if (act == ADVH_ACT_GELU) return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f));
+    if (act == ADVH_ACT_LEAKY) return x > 0.f ? x : slope * x;
+    return x;
+}
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void gemm_f16_kernel(const advh_gemm_desc p) {
+    constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 16, NI = TN / 16;
+    constexpr int NA = BM / 32, NB = BN / 32;      // 16-byte chunks per thread per K-step
+    static_assert(WM * WN == 4 && NB >= 1, "4 wavefronts");
+    __shared__ __attribute__((aligned(16))) char smem[(BM + BN) * BK * 2];
+    char* ldsA = smem;
+    char* ldsB = smem + BM * BK * 2;
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wm = wv / WN, wn = wv % WN;
+
+    // XCD-aware tile order: workgroups that share an XCD (id % 8) walk neighbouring tiles
+    const int tilesN = (p.N + BN - 1) / BN;
+    const int nwg = gridDim.x;
+    int id = blockIdx.x;
+    {
+        const int q8 = nwg / 8, r8 = nwg % 8, xcd = id % 8;
+        id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + id / 8;
+    }
+    const int tile_n = id % tilesN, tile_m = id / tilesN;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int z = blockIdx.z;
+
+    const _Float16* A0 = (const _Float16*)p.A0 + p.a_sZ[0] * z * 8;
+    const _Float16* A1 = (const _Float16*)p.A1 + p.a_sZ[1] * z * 8;
+    const _Float16* Wp = (const _Float16*)p.W + p.w_sZ * z;
+
+    // ---- loader setup: this thread's chunk column q and its NA rows' base offsets (chunk units)
+    const int ldrow = tid >> 3;                          // + 32*i
+    const int q = (tid & 7) ^ (ldrow & 7);               // logical K-chunk this lane fetches (swizzled source)
+    // row base of the "safe" row used by invalid rows (halo / M tail): first valid row of item 0
+    long safe0 = (long)p.h0 * p.a_sH[0] + (long)p.w0 * p.a_sW[0] + p.a_c0[0];
+    long safe1 = (long)p.h0 * p.a_sH[1] + (long)p.w0 * p.a_sW[1] + p.a_c0[1];
+    unsigned rb0[NA], rb1[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        unsigned m = m0 + ldrow + 32 * i;
+        unsigned w = m % (unsigned)p.Wg, t = m / (unsigned)p.Wg;
+        unsigned h = t % (unsigned)p.Hg, b = t / (unsigned)p.Hg;
+        bool ok = m < (unsigned)p.M && (int)h >= p.h0 && (int)h < p.h1 && (int)w >= p.w0 && (int)w < p.w1;
+        long r0 = ok ? (long)b * p.a_sB[0] + (long)h * p.a_sH[0] + (long)w * p.a_sW[0] + p.a_c0[0] : safe0;
+        long r1 = ok ? (long)b * p.a_sB[1] + (long)h * p.a_sH[1] + (long)w * p.a_sW[1] + p.a_c0[1] : safe1;
+        rb0[i] = (unsigned)r0;
+        rb1[i] = (unsigned)r1;
+    }
+    const _Float16* wrow[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) wrow[i] = Wp + (long)(n0 + ldrow + 32 * i) * p.Ktot + q * 8;
+
+    // ---- fragment read offsets (bytes) inside a tile: row r, logical chunk c -> (r*8 + (c ^ (r&7)))*16
+    const int fr = lane & 15, fq = lane >> 4;
+    int offA[2], offB[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        int c = (kk * 4 + fq) ^ (fr & 7);
+        offA[kk] = ((wm * TM + fr) * 8 + c) * 16;
+        offB[kk] = ((wn * TN + fr) * 8 + c) * 16;
+    }
+
+    f32x4 acc[NI][MI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.Ktot / BK;
+    int kq = p.ktab[q];
+    for (int kt = 0; kt < nk; ++kt) {
+        {
+            const bool s1 = kq < 0;
+            const unsigned ko = (unsigned)kq & 0x7fffffffu;
+            const _Float16* base = s1 ? A1 : A0;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const _Float16* g = base + ((unsigned long)((s1 ? rb1[i] : rb0[i]) + ko)) * 8;
+                __builtin_amdgcn_global_load_lds(GLOBAL_PTR(g), LDS_PTR(ldsA + (wv * 64 + 256 * i) * 16), 16, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < NB; ++i)
+                __builtin_amdgcn_global_load_lds(GLOBAL_PTR(wrow[i] + kt * BK),
+                                                 LDS_PTR(ldsB + (wv * 64 + 256 * i) * 16), 16, 0, 0);
+        }
+        if (kt + 1 < nk) kq = p.ktab[(kt + 1) * 8 + q];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            f16x8 a[MI], b[NI];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) a[mi] = *(const f16x8*)(ldsA + offA[kk] + mi * 16 * 128);
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) b[ni] = *(const f16x8*)(ldsB + offB[kk] + ni * 16 * 128);
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[ni], a[mi], acc[ni][mi], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds, per (ni, mi), channels n..n+3 of row m
+    const float* bias = p.bias ? p.bias + (long)p.bias_sZ * z : nullptr;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        unsigned m = m0 + wm * TM + mi * 16 + fr;
+        if (m >= (unsigned)p.M) continue;
+        unsigned w = m % (unsigned)p.Wg, t = m / (unsigned)p.Wg;
+        unsigned h = t % (unsigned)p.Hg, b = t / (unsigned)p.Hg;
+        bool ok = (int)h >= p.h0 && (int)h < p.h1 && (int)w >= p.w0 && (int)w < p.w1;
+        if (!ok && !p.halo_zero) continue;
+        long orow = (long)b * p.o_sB + (long)h * p.o_sH + (long)w * p.o_sW + p.o_c0 + p.o_sZ * z;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            int n = n0 + wn * TN + ni * 16 + fq * 4;
+            if (n >= p.N) continue;
+            long o = orow + (long)(n / p.n_div) * p.o_sNhi + (n % p.n_div);
+            f32x4 v = acc[ni][mi];
+            if (ok) {
+                if (bias) { float4 bb = *(const float4*)(bias + n); v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w; }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], p.act, p.slope);
+                if (p.resid) {
+                    if (p.resid_f32) {
+                        float4 rr = *(const float4*)((const float*)p.resid + o);
+                        v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
+                    } else {
+                        f16x4 rr = *(const f16x4*)((const _Float16*)p.resid + o);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
+                    }
+                }
+            } else {
+                v = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            if (p.out_f) *(float4*)((float*)p.out_f + o) = make_float4(v[0], v[1], v[2], v[3]);
+            if (p.out_h) {
+                f16x4 hv = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+                *(f16x4*)((_Float16*)p.out_h + o) = hv;
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch(const advh_gemm_desc& d, hipStream_t s) {
+    const int tilesM = (d.M + BM - 1) / BM, tilesN = (d.N + BN - 1) / BN;
+    if (tilesN * BN > d.w_rows) return ADVH_EINVAL;
+    dim3 grid(tilesM * tilesN, 1, d.nz > 0 ? d.nz : 1);
+    hipLaunchKernelGGL((gemm_f16_kernel<BM, BN, WM, WN>), grid, dim3(256), 0, s, d);
+    return ADVH_LAUNCH_CHECK();
+}
+
+}  // namespace advh
+
+using namespace advh;
+
+int advh_init_rest() { return ADVH_OK; }
+
+extern "C" int advh_gemm_f16(const advh_gemm_desc* d, int tile, advh_stream_t stream) {
+    if (!d || !d->A0 || !d->W || !d->ktab || (!d->out_h && !d->out_f)) return ADVH_EINVAL;
+    if (d->w_rows < d->N || d->M <= 0 || d->N <= 0 || d->Ktot <= 0 || d->Ktot % BK || d->N % 4 || d->Hg <= 0 || d->Wg <= 0) return ADVH_EINVAL;
+    if (d->n_div <= 0 || d->n_div % 4 || d->h0 < 0 || d->w0 < 0 || d->h1 > d->Hg || d->w1 > d->Wg || d->h0 >= d->h1 || d->w0 >= d->w1)
+        return ADVH_EINVAL;
+    if (d->act < ADVH_ACT_NONE || d->act > ADVH_ACT_LEAKY) return ADVH_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    if (tile == ADVH_TILE_AUTO) tile = d->N > 64 ? ADVH_TILE_128x128 : (d->N > 32 ? ADVH_TILE_256x64 : ADVH_TILE_256x32);
+    switch (tile) {
+        case ADVH_TILE_128x128: return launch<128, 128, 2, 2>(*d, s);
+        case ADVH_TILE_256x64: return launch<256, 64, 4, 1>(*d, s);
+        case ADVH_TILE_256x32: return launch<256, 32, 4, 1>(*d, s);
+        default: return ADVH_EINVAL;
+    }
+}

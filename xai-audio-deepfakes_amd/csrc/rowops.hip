@@ -1,0 +1,166 @@
+// Row-wise (HBM-bound) kernels of the embedder: LayerNorm (+GELU), the positional-conv operand
+// gather, and the time-pool + logistic-regression head.  One wavefront owns one row, loads are
+// 16-byte vectors, reductions are wave shuffles -- no LDS, no atomics.
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include "addvisor_hip.h"
+#include "common.h"
+
+namespace advh {
+
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
+
+// LayerNorm over the last dim C (C % 4 == 0, C <= 64*4*MAXV): torch.nn.functional.layer_norm semantics
+// (biased variance, eps inside the sqrt); two-pass in registers for accuracy.
+// in: fp32 or fp16 rows; out_f (fp32) and/or out_h (fp16); optional GELU after the affine.
+template <bool IN_F32, int MAXV>
+__global__ __launch_bounds__(256) void layernorm_kernel(const void* __restrict__ in, long in_ld,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        float* __restrict__ out_f, _Float16* __restrict__ out_h, long out_ld,
+                                                        int M, int C, float eps, int gelu) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    float v[MAXV][4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        int c = (i * 64 + lane) * 4;
+        if (c < C) {
+            if (IN_F32) {
+                float4 t = *(const float4*)((const float*)in + row * in_ld + c);
+                v[i][0] = t.x; v[i][1] = t.y; v[i][2] = t.z; v[i][3] = t.w;
+            } else {
+                f16x4 t = *(const f16x4*)((const _Float16*)in + row * in_ld + c);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[i][r] = (float)t[r];
+            }
+            s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        } else {
+            v[i][0] = v[i][1] = v[i][2] = v[i][3] = 0.f;
+        }
+    }
+    const float mean = wave_sum(s) / C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        int c = (i * 64 + lane) * 4;
+        if (c < C) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { float d = v[i][r] - mean; q += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / C + eps);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        int c = (i * 64 + lane) * 4;
+        if (c < C) {
+            float4 g = *(const float4*)(gamma + c), b = *(const float4*)(beta + c);
+            float o[4] = {(v[i][0] - mean) * rstd * g.x + b.x, (v[i][1] - mean) * rstd * g.y + b.y,
+                          (v[i][2] - mean) * rstd * g.z + b.z, (v[i][3] - mean) * rstd * g.w + b.w};
+            if (gelu) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = gelu_erf(o[r]);
+            }
+            if (out_f) *(float4*)(out_f + row * out_ld + c) = make_float4(o[0], o[1], o[2], o[3]);
+            if (out_h) {
+                f16x4 h = {(_Float16)o[0], (_Float16)o[1], (_Float16)o[2], (_Float16)o[3]};
+                *(f16x4*)(out_h + row * out_ld + c) = h;
+            }
+        }
+    }
+}
+
+// h [B][T][H] fp32 -> xg [G][B][P][Cg] fp16, P = T + K, data rows [K/2, K/2 + T), zeros elsewhere
+// (the zero padding of the positional Conv1d, modeling_wav2vec2.py:326-379).
+__global__ __launch_bounds__(256) void posconv_gather_kernel(const float* __restrict__ h, _Float16* __restrict__ xg,
+                                                             int B, int T, int H, int G, int K) {
+    const int Cg = H / G, P = T + K, c4 = Cg / 4;
+    const long total = (long)G * B * P * c4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int c = (int)(i % c4) * 4;
+        long r = i / c4;
+        int p = (int)(r % P);
+        long gb = r / P;
+        int b = (int)(gb % B), g = (int)(gb / B);
+        int t = p - K / 2;
+        f16x4 o = {0, 0, 0, 0};
+        if (t >= 0 && t < T) {
+            float4 v = *(const float4*)(h + ((long)b * T + t) * H + g * Cg + c);
+            o = f16x4{(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+        }
+        *(f16x4*)(xg + r * Cg + c) = o;
+    }
+}
+
+// logit[b] = mean_t(h[b,t,:]) . coef + intercept;  prob = sigmoid(logit)
+// (LMAC_metrics.py:130,146,156 pooling + classifier_embedder.py:34-38).  One workgroup per clip.
+__global__ __launch_bounds__(256) void pool_logreg_kernel(const float* __restrict__ h, const float* __restrict__ coef,
+                                                          float intercept, float* __restrict__ logit,
+                                                          float* __restrict__ prob, float* __restrict__ pooled,
+                                                          int T, int H) {
+    __shared__ float red[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* hb = h + (long)b * T * H;
+    float dot = 0.f;
+    for (int c = tid; c < H; c += 256) {
+        float s = 0.f;
+        for (int t = 0; t < T; ++t) s += hb[(long)t * H + c];
+        s /= T;
+        if (pooled) pooled[(long)b * H + c] = s;
+        dot += s * coef[c];
+    }
+    dot = wave_sum(dot);
+    if ((tid & 63) == 0) red[tid >> 6] = dot;
+    __syncthreads();
+    if (tid == 0) {
+        float z = (red[0] + red[1]) + (red[2] + red[3]) + intercept;
+        logit[b] = z;
+        prob[b] = 1.f / (1.f + expf(-z));
+    }
+}
+
+}  // namespace advh
+
+using namespace advh;
+
+extern "C" int advh_layernorm(const void* in, int in_is_f32, int64_t in_ld, const float* gamma, const float* beta,
+                              float* out_f, void* out_h, int64_t out_ld, int M, int C, float eps, int gelu,
+                              advh_stream_t stream) {
+    if (!in || !gamma || !beta || (!out_f && !out_h) || M <= 0 || C <= 0 || C % 4 || in_ld % 4 || out_ld % 4) return ADVH_EINVAL;
+    if (C > 64 * 4 * 8) return ADVH_EUNSUPPORTED;
+    dim3 grid((M + 3) / 4), block(256);
+    hipStream_t s = (hipStream_t)stream;
+#define LN_LAUNCH(F32, MV)                                                                                         \
+    hipLaunchKernelGGL((layernorm_kernel<F32, MV>), grid, block, 0, s, in, (long)in_ld, gamma, beta, out_f,        \
+                       (_Float16*)out_h, (long)out_ld, M, C, eps, gelu)
+    if (C <= 64 * 4 * 2) { if (in_is_f32) LN_LAUNCH(true, 2); else LN_LAUNCH(false, 2); }
+    else if (C <= 64 * 4 * 4) { if (in_is_f32) LN_LAUNCH(true, 4); else LN_LAUNCH(false, 4); }
+    else { if (in_is_f32) LN_LAUNCH(true, 8); else LN_LAUNCH(false, 8); }
+#undef LN_LAUNCH
+    return ADVH_LAUNCH_CHECK();
+}
+
+extern "C" int advh_posconv_gather(const float* h, void* xg, int B, int T, int H, int G, int K, advh_stream_t stream) {
+    if (!h || !xg || B <= 0 || T <= 0 || H <= 0 || G <= 0 || H % G || (H / G) % 8 || K <= 0 || K % 2) return ADVH_EINVAL;
+    long total = (long)G * B * (T + K) * (H / G / 4);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(posconv_gather_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, h, (_Float16*)xg, B, T, H, G, K);
+    return ADVH_LAUNCH_CHECK();
+}
+
+extern "C" int advh_pool_logreg(const float* h, const float* coef, float intercept, float* logit, float* prob,
+                                float* pooled, int B, int T, int H, advh_stream_t stream) {
+    if (!h || !coef || !logit || !prob || B <= 0 || T <= 0 || H <= 0) return ADVH_EINVAL;
+    hipLaunchKernelGGL(pool_logreg_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, h, coef, intercept, logit, prob, pooled, T, H);
+    return ADVH_LAUNCH_CHECK();
+}
