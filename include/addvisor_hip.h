@@ -116,6 +116,62 @@ typedef struct advh_gemm_desc {
 
 int advh_gemm_f16(const advh_gemm_desc* desc, int tile, advh_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * wav2vec2 waveform front end -- replaces zero_mean_unit_var_norm (classifier_embedder.py:59-63)
+ * and feature-encoder layer 0 (Conv1d(1,C0,10,stride 5) [+ GroupNorm(C0,C0) + GELU],
+ * transformers/models/wav2vec2/modeling_wav2vec2.py:254-323) behind AudioProcessor.extract_features
+ * (audioprocessor.py:69-77).
+ * wave [B][wave_stride] fp32 (n_in valid samples, padded / cropped to L);  w0 [C0][10] fp32.
+ * mode 0 ("group"): out = GELU(GroupNorm(conv)), gamma/beta [C0];  mode 1 ("layer"): out = conv + bias0.
+ * out: fp16 channels-last [B][P0][C0], rows t in [T0,P0) written as zeros; T0 = (L-10)/5 + 1.
+ * stats_ws: [B][2] fp32 workspace (clip mean, 1/(std+1e-7));  norm_ws: [B][C0][2] fp32 (mode 0).   */
+int advh_w2v2_frontend(const float* wave, int64_t wave_stride, int n_in, int B, int L, const float* w0,
+                       const float* bias0, const float* gamma, const float* beta, int mode, float* stats_ws,
+                       float* norm_ws, void* out, int T0, int P0, int C0, advh_stream_t stream);
+
+/* LayerNorm over the last dimension (+ optional GELU): nn.LayerNorm call sites of
+ * modeling_wav2vec2.py:275-299, 422-434, 575-654, 689-802.  in: [M][in_ld] fp32 (in_is_f32) or fp16;
+ * out_f (fp32) and/or out_h (fp16), row stride out_ld.  C % 4 == 0, C <= 2048. */
+int advh_layernorm(const void* in, int in_is_f32, int64_t in_ld, const float* gamma, const float* beta,
+                   float* out_f, void* out_h, int64_t out_ld, int M, int C, float eps, int gelu,
+                   advh_stream_t stream);
+
+/* Operand gather of the grouped positional Conv1d (modeling_wav2vec2.py:326-379):
+ * h [B][T][H] fp32 -> xg [G][B][T+K][H/G] fp16, data in rows [K/2, K/2+T), zero padding elsewhere. */
+int advh_posconv_gather(const float* h, void* xg, int B, int T, int H, int G, int K, advh_stream_t stream);
+
+/* softmax(Q K^T / sqrt(d)) V without mask (modeling_wav2vec2.py:438-548), T <= 256, d in {32, 64}.
+ * qkv [B*T][3H] fp16 (q | k | v), ctx [B*T][H] fp16. */
+int advh_attention_f16(const void* qkv, void* ctx, int B, int T, int H, int heads, advh_stream_t stream);
+
+/* Time mean-pool + logistic regression head: LMAC_metrics.py:130 pooling + TorchLogReg.forward
+ * (classifier_embedder.py:34-38).  h [B][T][H] fp32 -> logit[B], prob[B] (and pooled [B][H] if not NULL). */
+int advh_pool_logreg(const float* h, const float* coef, float intercept, float* logit, float* prob,
+                     float* pooled, int B, int T, int H, advh_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * U-Net layers that are not GEMM-shaped (addvisor.py:27-84).  mag is torch's [B][Fq][Tq] fp32; the
+ * H x W crop is taken by indexing.  NHWC maps are fp16 with a zero halo (PH, PW).
+ * advh_unet_stem : e1.block.0 Conv2d(1,32,(5,3),stride (2,1),pad (2,1)) + folded BN + LeakyReLU;
+ *                  wgt [32][15], out [B][H/2+2PH][W+2PW][32] (interior written).
+ * advh_unet_pack_x: channels [c0,c0+8) of the C-channel d1 concat map <- (mag, 0 x7)  (addvisor.py:79).
+ * advh_unet_head : mask_head Conv2d(32,1,1) + Sigmoid -> mask (and pre-sigmoid logits) [B][H][W] fp32. */
+int advh_unet_stem(const float* mag, int Fq, int Tq, int B, int H, int W, const float* wgt, const float* bias,
+                   void* out, int PH, int PW, float slope, advh_stream_t stream);
+int advh_unet_pack_x(const float* mag, int Fq, int Tq, int B, int H, int W, void* cat, int C, int c0, int PH, int PW,
+                     advh_stream_t stream);
+int advh_unet_head(const void* y, int B, int H, int W, int PH, int PW, const float* wgt, float bias, float* mask,
+                   float* logits, advh_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * LMAC faithfulness metrics -- replaces compute_faithfulness / compute_fidelity / compute_AD /
+ * compute_AI / compute_AG and their dataset means (LMAC_metrics.py:31-73, 164-172).
+ * predictions, theta_out, masked_predictions: [n] fp32 probabilities (clean, mask-in, mask-out).
+ * sums6 <- {sum faithfulness, sum fidelity, sum AD, sum AI, sum AG, n} in fp64, fixed summation
+ * order; per_clip (or NULL) <- [5][n] fp32 per-clip values. */
+int advh_lmac_metrics_accumulate(const float* predictions, const float* theta_out, const float* masked_predictions,
+                                 int n, double* sums6, float* per_clip, advh_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,225 @@
+"""Frozen wav2vec2 embedder + logreg head on the HIP kernels.
+
+Host-side orchestration of ``AudioProcessor.extract_features`` (audioprocessor.py:69-77) and the
+pool + ``TorchLogReg`` head (classifier_embedder.py:21-38, LMAC_metrics.py:130): the arithmetic of
+HF ``Wav2Vec2Model.forward`` (transformers/models/wav2vec2/modeling_wav2vec2.py:254-802, eval mode)
+is issued as a fixed sequence of C-ABI kernel launches on the current stream.  Nothing here computes
+on the host, and there is no fallback: every op is a hand-written gfx950 kernel.
+
+Precision: GEMM operands and the activations between GEMMs are fp16, accumulation is fp32, the
+residual stream / LayerNorm / softmax statistics are fp32.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib, gemm as G
+from .synthetic import EmbedderConfig
+
+
+def _f32(t, dev):
+    return t.detach().to(torch.float32).contiguous().to(dev)
+
+
+class _LN:
+    def __init__(self, sd, prefix, dev):
+        self.g, self.b = _f32(sd[prefix + ".weight"], dev), _f32(sd[prefix + ".bias"], dev)
+        self.C = self.g.numel()
+
+    def __call__(self, x: torch.Tensor, M: int, eps: float, out_f=None, out_h=None, gelu=False):
+        C = self.C
+        _lib.check(_lib.lib().advh_layernorm(
+            x.data_ptr(), int(x.dtype == torch.float32), C, self.g.data_ptr(), self.b.data_ptr(),
+            None if out_f is None else out_f.data_ptr(), None if out_h is None else out_h.data_ptr(), C, M, C,
+            eps, int(gelu), torch.cuda.current_stream().cuda_stream), "advh_layernorm")
+
+
+class HipEmbedder:
+    """``forward(wave[B, n]) -> hidden_states[layer_index] [B,T,H] fp32, logits [B,1], probs [B,1]``."""
+
+    def __init__(self, cfg: EmbedderConfig, sd: Dict[str, torch.Tensor], coef, intercept, device):
+        _lib.init()
+        self.cfg, self.dev = cfg, device
+        self.sd = {k: v.detach().float() for k, v in sd.items()}
+        if cfg.conv_kernel[0] != 10 or cfg.conv_stride[0] != 5:
+            raise ValueError("feature-encoder layer 0 must be Conv1d(k=10, stride=5)")
+        if cfg.head_dim not in (32, 64):
+            raise ValueError("attention kernel supports head_dim 32 / 64")
+        self.nl = min(cfg.layer_index, cfg.num_hidden_layers)
+        dev = device
+        p0 = "feature_extractor.conv_layers.0."
+        self.w0 = _f32(self.sd[p0 + "conv.weight"].reshape(cfg.conv_dim[0], 10), dev)
+        self.b0 = _f32(self.sd[p0 + "conv.bias"], dev) if cfg.conv_bias else None
+        self.layer_mode = cfg.feat_extract_norm == "layer"
+        self.fe_ln: List[Optional[_LN]] = []
+        for i in range(len(cfg.conv_dim)):
+            has = self.layer_mode or i == 0
+            self.fe_ln.append(_LN(self.sd, f"feature_extractor.conv_layers.{i}.layer_norm", dev) if has else None)
+        self.fp_ln = _LN(self.sd, "feature_projection.layer_norm", dev)
+        self.enc_ln = _LN(self.sd, "encoder.layer_norm", dev)
+        self.ln1 = [_LN(self.sd, f"encoder.layers.{l}.layer_norm", dev) for l in range(self.nl)]
+        self.ln2 = [_LN(self.sd, f"encoder.layers.{l}.final_layer_norm", dev) for l in range(self.nl)]
+        self.coef = _f32(torch.as_tensor(np.asarray(coef)).reshape(-1), dev)
+        self.intercept = float(np.asarray(intercept).reshape(-1)[0])
+        if self.coef.numel() != cfg.hidden_size:
+            raise ValueError("logreg coef_ must have hidden_size entries")
+        self._ws: Dict[Tuple[int, int], dict] = {}
+
+    # ------------------------------------------------------------------ planning (once per batch shape)
+    def _lengths(self, L: int) -> List[int]:
+        out, n = [], L
+        for k, s in zip(self.cfg.conv_kernel, self.cfg.conv_stride):
+            n = (n - k) // s + 1
+            out.append(n)
+        return out
+
+    def _workspace(self, B: int, L: int) -> dict:
+        key = (B, L)
+        if key in self._ws:
+            return self._ws[key]
+        cfg, dev, sd = self.cfg, self.dev, self.sd
+        Ls = self._lengths(L)
+        nfe = len(Ls)
+        strides = cfg.conv_stride
+        # padded row counts: P[i] = P[i+1] * stride[i+1], every P[i] >= L[i]
+        P_last = 1
+        for i in range(nfe):
+            prod = 1
+            for j in range(i + 1, nfe):
+                prod *= strides[j]
+            P_last = max(P_last, -(-Ls[i] // prod))
+        P = [0] * nfe
+        P[-1] = P_last
+        for i in range(nfe - 2, -1, -1):
+            P[i] = P[i + 1] * strides[i + 1]
+        T, H, I = Ls[-1], cfg.hidden_size, cfg.intermediate_size
+        M = B * T
+        C = cfg.conv_dim
+        h16, f32 = torch.float16, torch.float32
+        ws = dict(B=B, L=L, Ls=Ls, P=P, T=T, M=M)
+        ws["stats"] = torch.empty(B, 2, dtype=f32, device=dev)
+        ws["norm"] = torch.empty(B, C[0], 2, dtype=f32, device=dev)
+        ws["fe"] = [torch.empty(B * P[0] * C[0], dtype=h16, device=dev),
+                    torch.empty(B * P[1] * C[1], dtype=h16, device=dev)]
+        ws["feat"] = torch.empty(M, C[-1], dtype=h16, device=dev)
+        ws["featn"] = torch.empty(M, C[-1], dtype=h16, device=dev)
+        ws["h"] = torch.empty(M, H, dtype=f32, device=dev)
+        ws["h16"] = torch.empty(M, H, dtype=h16, device=dev)
+        ws["qkv"] = torch.empty(M, 3 * H, dtype=h16, device=dev)
+        ws["ctx"] = torch.empty(M, H, dtype=h16, device=dev)
+        ws["ffn"] = torch.empty(M, I, dtype=h16, device=dev)
+        K, Gp = cfg.num_conv_pos_embeddings, cfg.num_conv_pos_embedding_groups
+        Cg = H // Gp
+        ws["xg"] = torch.empty(Gp, B, T + K, Cg, dtype=h16, device=dev)
+        ws["logit"] = torch.empty(B, dtype=f32, device=dev)
+        ws["prob"] = torch.empty(B, dtype=f32, device=dev)
+
+        act = "none" if self.layer_mode else "gelu"
+        fe_plans = []
+        for i in range(1, nfe):
+            p = f"feature_extractor.conv_layers.{i}.conv."
+            fe_plans.append(G.plan_conv1d_cl(B, P[i - 1], P[i], Ls[i], sd[p + "weight"], sd.get(p + "bias"),
+                                             strides[i], act=act, compact_out=(i == nfe - 1), device=dev))
+        ws["fe_plans"] = fe_plans
+        ws["proj"] = G.plan_linear(M, sd["feature_projection.projection.weight"],
+                                   sd["feature_projection.projection.bias"], device=dev)
+        # positional conv: weight_norm folded (modeling_wav2vec2.py:326-357), one GEMM batched over groups
+        g0 = sd["encoder.pos_conv_embed.conv.parametrizations.weight.original0"]
+        v0 = sd["encoder.pos_conv_embed.conv.parametrizations.weight.original1"]
+        wpos = g0 * v0 / v0.pow(2).sum(dim=(0, 1), keepdim=True).sqrt()           # [H, Cg, K]
+        w2 = wpos.view(Gp, Cg, Cg, K).permute(0, 1, 3, 2).reshape(Gp, Cg, K * Cg)  # [g][n][(k, ci)]
+        cc = Cg // 8
+        ws["pos"] = G.GemmPlan(M=M, N=Cg, w2=w2, ktab=np.arange(K * cc, dtype=np.int64),
+                               sources=[G.Source((T + K) * cc, 0, cc, 0, sZ=B * (T + K) * cc)], Hg=1, Wg=T,
+                               window=(0, 1, 0, T), halo_zero=False, out=(T * H, 0, H, 0), n_div=G.round_up(Cg, 4),
+                               o_sZ=Cg, nz=Gp, bias=sd["encoder.pos_conv_embed.conv.bias"], bias_sZ=Cg, act="gelu",
+                               device=dev)
+        layers = []
+        for l in range(self.nl):
+            p = f"encoder.layers.{l}."
+            wqkv = torch.cat([sd[p + f"attention.{n}_proj.weight"] for n in ("q", "k", "v")], 0)
+            bqkv = torch.cat([sd[p + f"attention.{n}_proj.bias"] for n in ("q", "k", "v")], 0)
+            layers.append(dict(
+                qkv=G.plan_linear(M, wqkv, bqkv, device=dev),
+                out=G.plan_linear(M, sd[p + "attention.out_proj.weight"], sd[p + "attention.out_proj.bias"], device=dev),
+                ff1=G.plan_linear(M, sd[p + "feed_forward.intermediate_dense.weight"],
+                                  sd[p + "feed_forward.intermediate_dense.bias"], act="gelu", device=dev),
+                ff2=G.plan_linear(M, sd[p + "feed_forward.output_dense.weight"],
+                                  sd[p + "feed_forward.output_dense.bias"], device=dev)))
+        ws["layers"] = layers
+        ws["flops"] = (sum(p.flops for p in fe_plans) + ws["proj"].flops + ws["pos"].flops
+                       + sum(sum(pl.flops for pl in lay.values()) for lay in layers)
+                       + self.nl * 4.0 * B * T * T * H + 2.0 * B * Ls[0] * C[0] * 10)
+        self._ws[key] = ws
+        return ws
+
+    def flops(self, B: int, L: int) -> float:
+        """Algorithmic FLOPs (2*MAC) of one forward for B clips of L samples."""
+        return self._workspace(B, L)["flops"]
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, wave: torch.Tensor, length: Optional[int] = None, want_hidden: bool = True):
+        """Returns ``(hidden [B,T,H] fp32 or None, logits [B,1], probs [B,1])`` -- fresh tensors."""
+        if wave.dim() != 2 or wave.dtype != torch.float32 or not wave.is_cuda:
+            raise ValueError("wave must be a CUDA fp32 tensor [B, n]")
+        wave = wave.contiguous()
+        B, n_in = wave.shape
+        L = n_in if length is None else int(length)
+        cfg, lib = self.cfg, _lib.lib()
+        ws = self._workspace(B, L)
+        st = torch.cuda.current_stream().cuda_stream
+        Ls, P, T, M, H = ws["Ls"], ws["P"], ws["T"], ws["M"], cfg.hidden_size
+        eps = cfg.layer_norm_eps
+        C = cfg.conv_dim
+        a, bbuf = ws["fe"]
+        mode = 1 if self.layer_mode else 0
+        ln0 = self.fe_ln[0]
+        _lib.check(lib.advh_w2v2_frontend(
+            wave.data_ptr(), wave.stride(0), n_in, B, L, self.w0.data_ptr(),
+            None if self.b0 is None else self.b0.data_ptr(), ln0.g.data_ptr(), ln0.b.data_ptr(), mode,
+            ws["stats"].data_ptr(), ws["norm"].data_ptr(), a.data_ptr(), Ls[0], P[0], C[0], st), "advh_w2v2_frontend")
+        if self.layer_mode:
+            ln0(a, B * P[0], 1e-5, out_h=a, gelu=True)
+        cur, nxt = a, bbuf
+        nfe = len(Ls)
+        for i in range(1, nfe):
+            last = i == nfe - 1
+            dst = ws["feat"] if last else nxt
+            ws["fe_plans"][i - 1].run(cur, out_h=dst)
+            if self.layer_mode:
+                self.fe_ln[i](dst, M if last else B * P[i], 1e-5, out_h=dst, gelu=True)
+            cur, nxt = dst, cur
+        h, h16 = ws["h"], ws["h16"]
+        self.fp_ln(ws["feat"], M, eps, out_h=ws["featn"])
+        ws["proj"].run(ws["featn"], out_f=h)
+        K, Gp = cfg.num_conv_pos_embeddings, cfg.num_conv_pos_embedding_groups
+        _lib.check(lib.advh_posconv_gather(h.data_ptr(), ws["xg"].data_ptr(), B, T, H, Gp, K, st), "advh_posconv_gather")
+        ws["pos"].run(ws["xg"], out_f=h, resid=h)                     # h += gelu(pos_conv(h))
+        stable = cfg.do_stable_layer_norm
+        if not stable:
+            self.enc_ln(h, M, eps, out_f=h, out_h=h16)
+        for l in range(self.nl):
+            lay = ws["layers"][l]
+            if stable:
+                self.ln1[l](h, M, eps, out_h=h16)
+            lay["qkv"].run(h16, out_h=ws["qkv"])
+            _lib.check(lib.advh_attention_f16(ws["qkv"].data_ptr(), ws["ctx"].data_ptr(), B, T, H,
+                                              cfg.num_attention_heads, st), "advh_attention_f16")
+            lay["out"].run(ws["ctx"], out_f=h, resid=h)               # h = h + out_proj(ctx)
+            if stable:
+                self.ln2[l](h, M, eps, out_h=h16)
+            else:
+                self.ln1[l](h, M, eps, out_f=h, out_h=h16)
+            lay["ff1"].run(h16, out_h=ws["ffn"])
+            lay["ff2"].run(ws["ffn"], out_f=h, resid=h)               # h = h + ffn(h)
+            if not stable:
+                self.ln2[l](h, M, eps, out_f=h, out_h=h16)
+        if stable and self.nl == cfg.num_hidden_layers:
+            self.enc_ln(h, M, eps, out_f=h)
+        _lib.check(lib.advh_pool_logreg(h.data_ptr(), self.coef.data_ptr(), self.intercept, ws["logit"].data_ptr(),
+                                        ws["prob"].data_ptr(), None, B, T, H, st), "advh_pool_logreg")
+        hid = h.view(B, T, H).clone() if want_hidden else None
+        return hid, ws["logit"].clone().view(B, 1), ws["prob"].clone().view(B, 1)

@@ -1,0 +1,126 @@
+"""The ADDvisor U-Net mask decoder (addvisor.py:12-84) on the HIP kernels.
+
+Feature maps are zero-haloed NHWC fp16 (H = frequency bins, W = frames); every Conv2d /
+ConvTranspose2d is one implicit-GEMM launch (``gemm.plan_conv2d`` / ``plan_convT2d``) with BatchNorm
+(eval mode) folded into the weights, LeakyReLU(0.2) in the epilogue and the skip
+concatenations done by pointer.  The 1-channel stem and the 1x1 mask head are direct kernels.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from . import _lib, gemm as G
+
+SLOPE = 0.2
+BN_EPS = 1e-5
+
+
+def _fold_bn(sd, conv: str, bn: str) -> Tuple[torch.Tensor, torch.Tensor]:
+    w, b = sd[conv + ".weight"].float(), sd[conv + ".bias"].float()
+    s = sd[bn + ".weight"].float() / torch.sqrt(sd[bn + ".running_var"].float() + BN_EPS)
+    return w * s.view(-1, 1, 1, 1), (b - sd[bn + ".running_mean"].float()) * s + sd[bn + ".bias"].float()
+
+
+class HipUNet:
+    """``forward(mag [B, F>=H, T>=W] fp32) -> mask [B, H, W] fp32`` (H % 16 == 0, W % 4 == 0)."""
+
+    def __init__(self, sd: Dict[str, torch.Tensor], device):
+        _lib.init()
+        self.dev = device
+        self.sd = {k.replace("module.", ""): v.detach() for k, v in sd.items()}     # LMAC_metrics.py:23-25
+        w, b = _fold_bn(self.sd, "e1.block.0", "e1.block.1")
+        self.stem_w = w.reshape(32, 15).contiguous().to(device)
+        self.stem_b = b.contiguous().to(device)
+        self.head_w = self.sd["mask_head.0.weight"].float().reshape(32).contiguous().to(device)
+        self.head_b = float(self.sd["mask_head.0.bias"].float().reshape(-1)[0])
+        self._ws: Dict[Tuple[int, int, int], dict] = {}
+
+    def _workspace(self, B: int, H: int, W: int) -> dict:
+        key = (B, H, W)
+        if key in self._ws:
+            return self._ws[key]
+        if H % 16 or W % 4:
+            raise ValueError("U-Net input needs H % 16 == 0 and W % 4 == 0 (SURVEY.md D2)")
+        dev, sd = self.dev, self.sd
+        F = lambda h, w, c, ph, pw: G.FMap(B, h, w, c, ph, pw).alloc(dev)
+        m = dict(
+            x1a=F(H // 2, W, 32, 1, 1), x1=F(H // 2, W, 32, 2, 1),
+            x2a=F(H // 4, W, 64, 1, 1), x2=F(H // 4, W, 64, 1, 1),
+            x3a=F(H // 8, W // 2, 128, 1, 1), x3=F(H // 8, W // 2, 128, 1, 1),
+            x4a=F(H // 16, W // 4, 256, 1, 1), x4=F(H // 16, W // 4, 256, 2, 2),
+            b1=F(H // 16, W // 4, 512, 4, 4), b2=F(H // 16, W // 4, 512, 0, 0),
+            u4=F(H // 8, W // 2, 256, 1, 1), y4a=F(H // 8, W // 2, 256, 1, 1), y4=F(H // 8, W // 2, 256, 0, 0),
+            u3=F(H // 4, W, 128, 1, 1), y3a=F(H // 4, W, 128, 1, 1), y3=F(H // 4, W, 128, 0, 0),
+            u2=F(H // 2, W, 64, 1, 1), y2a=F(H // 2, W, 64, 1, 1), y2=F(H // 2, W, 64, 0, 0),
+            u1=F(H, W, 40, 1, 1), y1a=F(H, W, 32, 1, 1), y1=F(H, W, 32, 0, 0),
+        )
+        steps = []
+
+        def conv(srcs, dst, conv_name, bn_name, **kw):
+            w, b = _fold_bn(sd, conv_name, bn_name)
+            cin = sum(m[s].C for s in srcs)
+            if cin != w.shape[1]:                              # d1: 33 real channels live in a 40-wide map
+                w = torch.cat([w, w.new_zeros(w.shape[0], cin - w.shape[1], *w.shape[2:])], 1)
+            plan = G.plan_conv2d([m[s] for s in srcs], m[dst], w, b, slope=SLOPE, device=dev, **kw)
+            steps.append((plan, srcs, dst))
+
+        def block(srcs, mid, dst, name, **first):              # ConvBlock, addvisor.py:12-25
+            conv(srcs, mid, f"{name}.block.0", f"{name}.block.1", **first)
+            conv([mid], dst, f"{name}.block.3", f"{name}.block.4")
+
+        def up(src, dst, name, stride):
+            plan = G.plan_convT2d(m[src], m[dst], sd[name + ".weight"].float(), sd[name + ".bias"].float(),
+                                  stride=stride, device=dev)
+            steps.append((plan, [src], dst))
+
+        conv(["x1a"], "x1", "e1.block.3", "e1.block.4")        # e1.block.0 is the direct stem kernel
+        block(["x1"], "x2a", "x2", "e2", stride=(2, 1), padding=(2, 1))
+        block(["x2"], "x3a", "x3", "e3", stride=(2, 2))
+        block(["x3"], "x4a", "x4", "e4", stride=(2, 2))
+        conv(["x4"], "b1", "bottleneck.0", "bottleneck.1", padding=(2, 2), dilation=(2, 2))
+        conv(["b1"], "b2", "bottleneck.3", "bottleneck.4", padding=(4, 4), dilation=(4, 4))
+        up("b2", "u4", "up4", (2, 2))
+        block(["u4", "x3"], "y4a", "y4", "d4")
+        up("y4", "u3", "up3", (2, 2))
+        block(["u3", "x2"], "y3a", "y3", "d3")
+        up("y3", "u2", "up2", (2, 1))
+        block(["u2", "x1"], "y2a", "y2", "d2")
+        up("y2", "u1", "up1", (2, 1))
+        block(["u1"], "y1a", "y1", "d1")
+        ws = dict(maps=m, steps=steps, mask=torch.empty(B, H, W, dtype=torch.float32, device=dev),
+                  logits=torch.empty(B, H, W, dtype=torch.float32, device=dev))
+        ws["flops"] = sum(s[0].flops for s in steps) + 2.0 * B * (H // 2) * W * 32 * 15 + 2.0 * B * H * W * 32
+        self._ws[key] = ws
+        return ws
+
+    def flops(self, B: int, H: int, W: int) -> float:
+        return self._workspace(B, H, W)["flops"]
+
+    def forward(self, mag: torch.Tensor, H: int = 512, W: Optional[int] = None, want_logits: bool = False):
+        """``mag``: fp32 CUDA ``[B, Fq, Tq]`` (t fastest); the ``H x W`` crop is read in place."""
+        if mag.dim() != 3 or mag.dtype != torch.float32 or not mag.is_cuda:
+            raise ValueError("mag must be a CUDA fp32 tensor [B, F, T]")
+        mag = mag.contiguous()
+        B, Fq, Tq = mag.shape
+        W = (Tq // 4) * 4 if W is None else W
+        if H > Fq or W > Tq:
+            raise ValueError("crop exceeds the spectrogram")
+        ws = self._workspace(B, H, W)
+        m, lib = ws["maps"], _lib.lib()
+        st = torch.cuda.current_stream().cuda_stream
+        x1a, u1 = m["x1a"], m["u1"]
+        _lib.check(lib.advh_unet_stem(mag.data_ptr(), Fq, Tq, B, H, W, self.stem_w.data_ptr(), self.stem_b.data_ptr(),
+                                      x1a.t.data_ptr(), x1a.PH, x1a.PW, SLOPE, st), "advh_unet_stem")
+        _lib.check(lib.advh_unet_pack_x(mag.data_ptr(), Fq, Tq, B, H, W, u1.t.data_ptr(), u1.C, 32, u1.PH, u1.PW, st),
+                   "advh_unet_pack_x")
+        for plan, srcs, dst in ws["steps"]:
+            a0 = m[srcs[0]].t
+            a1 = m[srcs[1]].t if len(srcs) > 1 else None
+            plan.run(a0, a1, out_h=m[dst].t)
+        y1 = m["y1"]
+        _lib.check(lib.advh_unet_head(y1.t.data_ptr(), B, H, W, y1.PH, y1.PW, self.head_w.data_ptr(), self.head_b,
+                                      ws["mask"].data_ptr(), ws["logits"].data_ptr(), st), "advh_unet_head")
+        mask = ws["mask"].clone()
+        return (mask, ws["logits"].clone()) if want_logits else mask

@@ -1,0 +1,136 @@
+// Fused self-attention for short sequences (T <= 256): softmax(Q K^T / sqrt(d)) V, no mask
+// (transformers/.../modeling_wav2vec2.py:438-548; the reference forces the math SDP path,
+// train_addvisor.py:21-23).  wav2vec2 sees T = 199 frames for a 4 s clip (249 for 5 s), so the whole
+// K and V of one (clip, head) fit in LDS and the softmax is single-pass: no online rescaling.
+//
+// One workgroup per (head, clip); each of its 4 wavefronts owns 16-query tiles.  S^T = K Q^T is
+// computed with the KEY on the MFMA row, so a lane ends up with 4*NT scores of ONE query: the row
+// max / sum are register reductions plus two cross-lane steps, and the fp16 P registers are already
+// the B operand of O^T = V^T P^T (cdna_hip_programming.md §3 "An accumulator tile as the next MFMA's
+// operand": the k order inside a 32-key step is permuted, and V^T is read from LDS in that same order).
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include "addvisor_hip.h"
+#include "common.h"
+
+namespace advh {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int NT, int D>
+__global__ __launch_bounds__(256) void attention_kernel(const _Float16* __restrict__ qkv, _Float16* __restrict__ ctx,
+                                                        int T, int H, float scale) {
+    constexpr int NKEY = NT * 16, CH = D / 8, VP = NKEY + 8, NS = (NT + 1) / 2, KK = D / 32, DT = D / 16;
+    __shared__ __attribute__((aligned(16))) _Float16 Ks[NKEY * D];
+    __shared__ __attribute__((aligned(16))) _Float16 Vt[D * VP];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int head = blockIdx.x, b = blockIdx.y;
+    const long ld = 3L * H;
+    const _Float16* base = qkv + (long)b * T * ld + head * D;
+
+    // ---- stage K (row-major, 16-byte chunks XOR-swizzled by row) and V^T; keys >= T are zero
+    for (int i = tid; i < NKEY * CH; i += 256) {
+        int key = i / CH, c = i % CH;
+        f16x8 kv = {0, 0, 0, 0, 0, 0, 0, 0}, vv = kv;
+        if (key < T) {
+            kv = *(const f16x8*)(base + (long)key * ld + H + c * 8);
+            vv = *(const f16x8*)(base + (long)key * ld + 2 * H + c * 8);
+        }
+        *(f16x8*)(Ks + key * D + ((c ^ (key & (CH - 1))) * 8)) = kv;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) Vt[(c * 8 + j) * VP + key] = vv[j];
+    }
+    __syncthreads();
+
+    const int fr = lane & 15, g = lane >> 4;
+    for (int qt = wv; qt * 16 < T; qt += 4) {
+        int qrow = qt * 16 + fr;
+        int qr = qrow < T ? qrow : T - 1;
+        f16x8 qf[KK];
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) qf[kk] = *(const f16x8*)(base + (long)qr * ld + kk * 32 + g * 8);
+
+        // S^T tiles: rows = keys (4g + r within the tile), column = this lane's query
+        f32x4 s[NT];
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+            s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) {
+                int key = kt * 16 + fr, c = kk * 4 + g;
+                f16x8 kf = *(const f16x8*)(Ks + key * D + ((c ^ (key & (CH - 1))) * 8));
+                s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[kk], s[kt], 0, 0, 0);
+            }
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = (kt * 16 + g * 4 + r < T) ? s[kt][r] * scale : -INFINITY;
+                s[kt][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { float e = expf(s[kt][r] - mx); s[kt][r] = e; sum += e; }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.f / sum;
+
+        // P as the B operand of each 32-key step: elements 0-3 from tile 2s, 4-7 from tile 2s+1
+        f16x8 pf[NS];
+#pragma unroll
+        for (int ss = 0; ss < NS; ++ss) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                pf[ss][r] = (_Float16)(s[2 * ss][r] * inv);
+                pf[ss][4 + r] = (2 * ss + 1 < NT) ? (_Float16)(s[(2 * ss + 1 < NT) ? 2 * ss + 1 : 0][r] * inv) : (_Float16)0.f;
+            }
+        }
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ss = 0; ss < NS; ++ss) {
+                const _Float16* vr = Vt + (dt * 16 + fr) * VP + ss * 32 + g * 4;
+                f16x4 lo = *(const f16x4*)vr;
+                f16x4 hi = (2 * ss + 1 < NT) ? *(const f16x4*)(vr + 16) : f16x4{0, 0, 0, 0};
+                f16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                o = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[ss], o, 0, 0, 0);
+            }
+            if (qrow < T) {
+                f16x4 hv = {(_Float16)o[0], (_Float16)o[1], (_Float16)o[2], (_Float16)o[3]};
+                *(f16x4*)(ctx + ((long)b * T + qrow) * H + head * D + dt * 16 + g * 4) = hv;
+            }
+        }
+    }
+}
+
+}  // namespace advh
+
+using namespace advh;
+
+extern "C" int advh_attention_f16(const void* qkv, void* ctx, int B, int T, int H, int heads, advh_stream_t stream) {
+    if (!qkv || !ctx || B <= 0 || T <= 0 || heads <= 0 || H % heads) return ADVH_EINVAL;
+    const int D = H / heads;
+    if (T > 256 || (D != 64 && D != 32)) return ADVH_EUNSUPPORTED;
+    const float scale = 1.f / sqrtf((float)D);
+    dim3 grid(heads, B), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    const int nt = (T + 15) / 16;
+#define ATT(NT_, D_) hipLaunchKernelGGL((attention_kernel<NT_, D_>), grid, block, 0, s, (const _Float16*)qkv, (_Float16*)ctx, T, H, scale)
+    if (D == 64) {
+        if (nt <= 4) ATT(4, 64); else if (nt <= 8) ATT(8, 64); else if (nt <= 13) ATT(13, 64); else ATT(16, 64);
+    } else {
+        if (nt <= 4) ATT(4, 32); else if (nt <= 8) ATT(8, 32); else if (nt <= 13) ATT(13, 32); else ATT(16, 32);
+    }
+#undef ATT
+    return ADVH_LAUNCH_CHECK();
+}

@@ -1,0 +1,174 @@
+// wav2vec2 waveform front end: clip normaliser + feature-encoder layer 0.
+//
+//   zero_mean_unit_var_norm           classifier_embedder.py:59-63 (unbiased std, eps added to std)
+//   Conv1d(1 -> C0, k=10, s=5)        transformers/.../modeling_wav2vec2.py:254-323 (layer_id 0)
+//   GroupNorm(C0 groups) + GELU       :302-323  ("group" feature extractor, wav2vec2-base)
+//
+// Layer 0 has one input channel, so it is 10 MACs per output and HBM-bound on its fp16 output
+// ([B][P0][C0] channels-last, 13 MB per 4 s clip): no matrix cores.  GroupNorm with one group per
+// channel normalises over TIME; because the layer is linear in the waveform its per-channel mean
+// and variance follow exactly from the 10 x 10 Gram matrix of the strided input windows, so the
+// statistics cost one pass over the 256 KB clip instead of two passes over the 13 MB activation:
+//     mean_c = sum_k w[c,k] S1[k],   E[y_c^2] = sum_{k,k'} w[c,k] w[c,k'] S2[k,k'].
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include "addvisor_hip.h"
+#include "common.h"
+
+namespace advh {
+
+constexpr int K0 = 10, S0 = 5;     // kernel / stride of feature-encoder layer 0 (every wav2vec2 config)
+
+__device__ __forceinline__ double block_sum_d(double v, double* red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double s = 0;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) s += red[i];
+    return s;
+}
+
+// stats[b] = (mean, 1/(std_unbiased + 1e-7)) of the clip padded / cropped to L samples
+__global__ __launch_bounds__(256) void wave_stats_kernel(const float* __restrict__ wave, long stride, int n_in, int L,
+                                                         float2* __restrict__ stats) {
+    __shared__ double red[4];
+    const float* w = wave + (long)blockIdx.x * stride;
+    const int n = n_in < L ? n_in : L;
+    double s = 0;
+    for (int i = threadIdx.x; i < n; i += 256) s += w[i];
+    const double mean = block_sum_d(s, red) / L;
+    double q = 0;
+    for (int i = threadIdx.x; i < n; i += 256) { double d = w[i] - mean; q += d * d; }
+    q = block_sum_d(q, red) + (double)(L - n) * mean * mean;       // zero-padded tail
+    if (threadIdx.x == 0) {
+        float sd = (float)sqrt(q / (L - 1));
+        stats[blockIdx.x] = make_float2((float)mean, 1.f / (sd + 1e-7f));
+    }
+}
+
+__device__ __forceinline__ float load_norm(const float* w, int i, int n, float mean, float rstd) {
+    float x = i < n ? w[i] : 0.f;
+    return (x - mean) * rstd;
+}
+
+// GroupNorm statistics from the Gram matrix; norm[b][c] = (scale, shift) with
+// y_norm = conv(xhat)[c] * scale + shift  (gamma, beta and eps = 1e-5 folded in).
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ wave, long stride, int n_in, int L,
+                                                       const float2* __restrict__ stats, const float* __restrict__ w0,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       float2* __restrict__ norm, int T0, int C0) {
+    __shared__ double red[4];
+    __shared__ double S[K0 + K0 * K0];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* w = wave + (long)b * stride;
+    const int n = n_in < L ? n_in : L;
+    const float2 st = stats[b];
+    double s1[K0], s2[K0 * (K0 + 1) / 2];
+#pragma unroll
+    for (int k = 0; k < K0; ++k) s1[k] = 0;
+#pragma unroll
+    for (int k = 0; k < K0 * (K0 + 1) / 2; ++k) s2[k] = 0;
+    for (int t = tid; t < T0; t += 256) {
+        float x[K0];
+#pragma unroll
+        for (int k = 0; k < K0; ++k) x[k] = load_norm(w, S0 * t + k, n, st.x, st.y);
+        int idx = 0;
+#pragma unroll
+        for (int k = 0; k < K0; ++k) {
+            s1[k] += x[k];
+#pragma unroll
+            for (int j = k; j < K0; ++j) s2[idx++] += (double)x[k] * x[j];
+        }
+    }
+    {
+        int idx = 0;
+        for (int k = 0; k < K0; ++k) {
+            double v = block_sum_d(s1[k], red);
+            if (tid == 0) S[k] = v / T0;
+        }
+        for (int k = 0; k < K0; ++k)
+            for (int j = k; j < K0; ++j) {
+                double v = block_sum_d(s2[idx++], red);
+                if (tid == 0) { S[K0 + k * K0 + j] = v / T0; S[K0 + j * K0 + k] = v / T0; }
+            }
+    }
+    __syncthreads();
+    for (int c = tid; c < C0; c += 256) {
+        double m = 0, e2 = 0;
+        for (int k = 0; k < K0; ++k) {
+            double wk = w0[c * K0 + k];
+            m += wk * S[k];
+            for (int j = 0; j < K0; ++j) e2 += wk * (double)w0[c * K0 + j] * S[K0 + k * K0 + j];
+        }
+        double var = e2 - m * m;
+        if (var < 0) var = 0;
+        float sc = gamma[c] * (float)(1.0 / sqrt(var + 1e-5));
+        norm[(long)b * C0 + c] = make_float2(sc, beta[c] - (float)m * sc);
+    }
+}
+
+// out[b][t][c] = GELU(conv * scale + shift)   (mode 0, "group")   or   conv + bias   (mode 1, raw: the
+// LayerNorm + GELU of the "layer" feature extractor follow as a row kernel).  Rows t in [T0, P0) = 0.
+constexpr int TT = 64;
+__global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ wave, long stride, int n_in, int L,
+                                                    const float2* __restrict__ stats, const float* __restrict__ w0,
+                                                    const float* __restrict__ bias, const float2* __restrict__ norm,
+                                                    _Float16* __restrict__ out, int T0, int P0, int C0, int mode) {
+    __shared__ float xs[TT * S0 + K0];
+    const int b = blockIdx.y, t0 = blockIdx.x * TT, tid = threadIdx.x;
+    const float* w = wave + (long)b * stride;
+    const int n = n_in < L ? n_in : L;
+    const float2 st = stats[b];
+    for (int i = tid; i < TT * S0 + K0; i += 256) xs[i] = load_norm(w, S0 * t0 + i, n, st.x, st.y);
+    __syncthreads();
+    const int c = 2 * tid;
+    if (c >= C0) return;
+    float wa[K0], wb[K0];
+#pragma unroll
+    for (int k = 0; k < K0; ++k) { wa[k] = w0[c * K0 + k]; wb[k] = w0[(c + 1) * K0 + k]; }
+    float sa = 1.f, ha = 0.f, sb = 1.f, hb = 0.f;
+    if (mode == 0) {
+        float2 na = norm[(long)b * C0 + c], nb = norm[(long)b * C0 + c + 1];
+        sa = na.x; ha = na.y; sb = nb.x; hb = nb.y;
+    } else if (bias) {
+        ha = bias[c]; hb = bias[c + 1];
+    }
+    const int tend = min(TT, P0 - t0);
+    for (int t = 0; t < tend; ++t) {
+        float ya = 0.f, yb = 0.f;
+        if (t0 + t < T0) {
+#pragma unroll
+            for (int k = 0; k < K0; ++k) { float x = xs[S0 * t + k]; ya = fmaf(wa[k], x, ya); yb = fmaf(wb[k], x, yb); }
+            ya = ya * sa + ha; yb = yb * sb + hb;
+            if (mode == 0) {
+                ya = 0.5f * ya * (1.f + erff(ya * 0.70710678118654752440f));
+                yb = 0.5f * yb * (1.f + erff(yb * 0.70710678118654752440f));
+            }
+        }
+        __half2 h = __floats2half2_rn(ya, yb);
+        *(__half2*)(out + ((long)b * P0 + t0 + t) * C0 + c) = h;
+    }
+}
+
+}  // namespace advh
+
+using namespace advh;
+
+extern "C" int advh_w2v2_frontend(const float* wave, int64_t wave_stride, int n_in, int B, int L, const float* w0,
+                                  const float* bias0, const float* gamma, const float* beta, int mode, float* stats_ws,
+                                  float* norm_ws, void* out, int T0, int P0, int C0, advh_stream_t stream) {
+    if (!wave || !w0 || !stats_ws || !out || B <= 0 || L < K0 || n_in <= 0 || C0 <= 0 || C0 > 512 || (C0 & 1)) return ADVH_EINVAL;
+    if (T0 != (L - K0) / S0 + 1 || P0 < T0 || wave_stride < (n_in < L ? n_in : L)) return ADVH_EINVAL;
+    if (mode == 0 && (!gamma || !beta || !norm_ws)) return ADVH_EINVAL;
+    if (mode != 0 && mode != 1) return ADVH_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(wave_stats_kernel, dim3(B), dim3(256), 0, s, wave, (long)wave_stride, n_in, L, (float2*)stats_ws);
+    if (mode == 0)
+        hipLaunchKernelGGL(gn_stats_kernel, dim3(B), dim3(256), 0, s, wave, (long)wave_stride, n_in, L,
+                           (const float2*)stats_ws, w0, gamma, beta, (float2*)norm_ws, T0, C0);
+    hipLaunchKernelGGL(conv0_kernel, dim3((P0 + TT - 1) / TT, B), dim3(256), 0, s, wave, (long)wave_stride, n_in, L,
+                       (const float2*)stats_ws, w0, bias0, (const float2*)norm_ws, (_Float16*)out, T0, P0, C0, mode);
+    return ADVH_LAUNCH_CHECK();
+}

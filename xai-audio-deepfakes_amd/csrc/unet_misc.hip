@@ -1,0 +1,116 @@
+// The three U-Net layers that are not GEMM-shaped (addvisor.py:27-84): the 1-channel stem
+// convolution, the copy of the input magnitude into the last skip-concat buffer, and the
+// 1x1 mask head + sigmoid.  All HBM-bound, one thread per spatial position, 16-byte vectors on the
+// channels-last side.  H = frequency bins, W = frames; the magnitude arrives as torch's
+// [B][F][T] fp32 (t fastest), cropped to H x W by indexing, never copied.
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include "addvisor_hip.h"
+#include "common.h"
+
+namespace advh {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+// e1.block.0: Conv2d(1, 32, (5,3), stride (2,1), padding (2,1)) with BatchNorm folded, LeakyReLU(0.2)
+// (addvisor.py:31, 15-17).  out: zero-haloed NHWC fp16 [B][Ho+2PH][W+2PW][32], interior written.
+__global__ __launch_bounds__(256) void unet_stem_kernel(const float* __restrict__ mag, int Fq, int Tq, int H, int W,
+                                                        const float* __restrict__ wgt /*[32][15]*/,
+                                                        const float* __restrict__ bias, _Float16* __restrict__ out,
+                                                        int PH, int PW, float slope, long total) {
+    __shared__ float ws[32 * 15 + 32];
+    for (int i = threadIdx.x; i < 32 * 15 + 32; i += 256) ws[i] = i < 480 ? wgt[i] : bias[i - 480];
+    __syncthreads();
+    const int Ho = H / 2;
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    int w = (int)(i % W);
+    long r = i / W;
+    int ho = (int)(r % Ho), b = (int)(r / Ho);
+    float x[15];
+#pragma unroll
+    for (int kh = 0; kh < 5; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            int h = 2 * ho + kh - 2, ww = w + kw - 1;
+            x[kh * 3 + kw] = (h >= 0 && h < H && ww >= 0 && ww < W) ? mag[((long)b * Fq + h) * Tq + ww] : 0.f;
+        }
+    _Float16* o = out + (((long)b * (Ho + 2 * PH) + ho + PH) * (W + 2 * PW) + w + PW) * 32;
+#pragma unroll
+    for (int c8 = 0; c8 < 4; ++c8) {
+        f16x8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            int c = c8 * 8 + j;
+            float y = ws[480 + c];
+#pragma unroll
+            for (int k = 0; k < 15; ++k) y = fmaf(ws[c * 15 + k], x[k], y);
+            v[j] = (_Float16)(y > 0.f ? y : slope * y);
+        }
+        *(f16x8*)(o + c8 * 8) = v;
+    }
+}
+
+// channels [c0, c0+8) of the d1 skip-concat buffer <- (x, 0, 0, 0, 0, 0, 0, 0)   (torch.cat([y1, x]), addvisor.py:79)
+__global__ __launch_bounds__(256) void unet_pack_x_kernel(const float* __restrict__ mag, int Fq, int Tq, int H, int W,
+                                                          _Float16* __restrict__ cat, int C, int c0, int PH, int PW, long total) {
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    int w = (int)(i % W);
+    long r = i / W;
+    int h = (int)(r % H), b = (int)(r / H);
+    f16x8 v = {(_Float16)mag[((long)b * Fq + h) * Tq + w], 0, 0, 0, 0, 0, 0, 0};
+    *(f16x8*)(cat + (((long)b * (H + 2 * PH) + h + PH) * (W + 2 * PW) + w + PW) * C + c0) = v;
+}
+
+// mask[b][h][w] = sigmoid(sum_c y[b,h,w,c] * w[c] + bias)   (mask_head, addvisor.py:57-60); fp32 out, w fastest
+__global__ __launch_bounds__(256) void unet_head_kernel(const _Float16* __restrict__ y, int H, int W, int PH, int PW,
+                                                        const float* __restrict__ wgt, float bias,
+                                                        float* __restrict__ mask, float* __restrict__ logits, long total) {
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    int w = (int)(i % W);
+    long r = i / W;
+    int h = (int)(r % H), b = (int)(r / H);
+    const _Float16* p = y + (((long)b * (H + 2 * PH) + h + PH) * (W + 2 * PW) + w + PW) * 32;
+    float acc = bias;
+#pragma unroll
+    for (int c8 = 0; c8 < 4; ++c8) {
+        f16x8 v = *(const f16x8*)(p + c8 * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc = fmaf((float)v[j], wgt[c8 * 8 + j], acc);
+    }
+    if (logits) logits[i] = acc;
+    mask[i] = 1.f / (1.f + expf(-acc));
+}
+
+}  // namespace advh
+
+using namespace advh;
+
+extern "C" int advh_unet_stem(const float* mag, int Fq, int Tq, int B, int H, int W, const float* wgt, const float* bias,
+                              void* out, int PH, int PW, float slope, advh_stream_t stream) {
+    if (!mag || !wgt || !bias || !out || B <= 0 || H <= 0 || (H & 1) || W <= 0 || H > Fq || W > Tq || PH < 0 || PW < 0) return ADVH_EINVAL;
+    long total = (long)B * (H / 2) * W;
+    hipLaunchKernelGGL(unet_stem_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, mag, Fq, Tq, H, W,
+                       wgt, bias, (_Float16*)out, PH, PW, slope, total);
+    return ADVH_LAUNCH_CHECK();
+}
+
+extern "C" int advh_unet_pack_x(const float* mag, int Fq, int Tq, int B, int H, int W, void* cat, int C, int c0, int PH, int PW,
+                                advh_stream_t stream) {
+    if (!mag || !cat || B <= 0 || H <= 0 || W <= 0 || H > Fq || W > Tq || C % 8 || c0 % 8 || c0 + 8 > C) return ADVH_EINVAL;
+    long total = (long)B * H * W;
+    hipLaunchKernelGGL(unet_pack_x_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, mag, Fq, Tq, H, W,
+                       (_Float16*)cat, C, c0, PH, PW, total);
+    return ADVH_LAUNCH_CHECK();
+}
+
+extern "C" int advh_unet_head(const void* y, int B, int H, int W, int PH, int PW, const float* wgt, float bias, float* mask,
+                              float* logits, advh_stream_t stream) {
+    if (!y || !wgt || !mask || B <= 0 || H <= 0 || W <= 0) return ADVH_EINVAL;
+    long total = (long)B * H * W;
+    hipLaunchKernelGGL(unet_head_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const _Float16*)y, H, W,
+                       PH, PW, wgt, bias, mask, logits, total);
+    return ADVH_LAUNCH_CHECK();
+}
