@@ -1,0 +1,83 @@
+"""GPU parity of the whole explanation path and of the LMAC metric kernel against the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from addvisor_hip import pipeline as P, synthetic as syn
+from oracle import lmac_ref
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+
+TOL_PROB = 1e-2      # classifier probabilities through fp16 GEMMs (stated; measured ~2e-3)
+
+
+@pytest.mark.parametrize("domain", ["log1p", "linear"])
+def test_explain_tiny_vs_oracle(gpu_device, domain):
+    cfg = syn.tiny_config(False)
+    emb_sd, unet_sd = syn.embedder_weights(cfg), syn.unet_weights()
+    coef, icpt = syn.logreg_weights(cfg.hidden_size)
+    pipe = P.ExplainPipeline(cfg, emb_sd, coef, icpt, unet_sd, gpu_device, audio_length=1, domain=domain)
+    w = syn.make_clips(4, 16000, seed=77)
+    out = pipe.explain(w.to(gpu_device), keep=True)
+    ref = lmac_ref.explain(w, emb_sd, cfg, coef, icpt, unet_sd, audio_length=1, domain=domain)
+    for k in ("predictions", "theta_out", "masked_predictions"):
+        assert (out[k].cpu() - ref[k]).abs().max().item() <= TOL_PROB, k
+    assert (out["mask"].cpu() - ref["mask"]).abs().max().item() <= 1.5e-2
+    assert (out["wave_in"].cpu() - ref["wave_in"]).abs().max().item() <= 2e-2      # follows the mask tolerance
+    assert (out["wave_out"].cpu() - ref["wave_out"]).abs().max().item() <= 2e-2
+
+
+def test_explain_base_4s_vs_oracle(gpu_device):
+    """BASELINE models (wav2vec2-base + U-Net) on two 4 s clips."""
+    cfg = syn.base_config()
+    emb_sd, unet_sd = syn.embedder_weights(cfg), syn.unet_weights()
+    coef, icpt = syn.logreg_weights(cfg.hidden_size)
+    pipe = P.ExplainPipeline(cfg, emb_sd, coef, icpt, unet_sd, gpu_device, audio_length=4)
+    w = syn.make_clips(2, 64000)
+    out = pipe.explain(w.to(gpu_device))
+    ref = lmac_ref.explain(w, emb_sd, cfg, coef, icpt, unet_sd, audio_length=4)
+    for k in ("predictions", "theta_out", "masked_predictions"):
+        err = (out[k].cpu() - ref[k]).abs().max().item()
+        print(k, "max err", err, "values", out[k].view(-1).tolist(), ref[k].view(-1).tolist())
+        assert err <= TOL_PROB, k
+
+
+def test_lmac_metrics_kernel(gpu_device):
+    r = np.random.Generator(np.random.PCG64(3))
+    n = 1000
+    p, t, o = (torch.from_numpy(r.uniform(0, 1, size=(n, 1)).astype(np.float32)) for _ in range(3))
+    p[:5, 0] = torch.tensor([0.9, 0.2, 0.5, 0.5, 0.7])            # ties at 0.5 included
+    t[:5, 0] = torch.tensor([0.8, 0.1, 0.6, 0.5, 0.3])
+    o[:5, 0] = torch.tensor([0.4, 0.6, 0.5, 0.2, 0.9])
+    d = gpu_device
+    got, pc = P.lmac_metrics(p.to(d), t.to(d), o.to(d), per_clip=True)
+    ref = lmac_ref.lmac_summary(p, t, o)
+    for k in ref:
+        assert abs(got[k] - ref[k]) <= 1e-5 * max(1.0, abs(ref[k])), (k, got[k], ref[k])
+    pc = pc.cpu()
+    assert torch.equal(pc[0], lmac_ref.compute_faithfulness(p, o))          # per-clip values: bit-exact fp32
+    assert torch.equal(pc[1], lmac_ref.compute_fidelity(t, p).view(-1))
+    assert torch.allclose(pc[2], lmac_ref.compute_AD(t, p), rtol=1e-6, atol=1e-6)
+    assert torch.equal(pc[3], lmac_ref.compute_AI(t, p))
+    assert torch.allclose(pc[4], lmac_ref.compute_AG(t, p), rtol=1e-6, atol=1e-5)
+
+
+def test_full_batch_properties(gpu_device):
+    """BASELINE batch (64 x 4 s): size-independent properties, no oracle needed."""
+    cfg = syn.base_config()
+    pipe = P.ExplainPipeline(cfg, syn.embedder_weights(cfg), *syn.logreg_weights(cfg.hidden_size), syn.unet_weights(),
+                             gpu_device, audio_length=4, domain="linear")
+    w = syn.make_clips(64, 64000).to(gpu_device)
+    out = pipe.explain(w, keep=True)
+    again = pipe.explain(w)
+    for k in ("predictions", "theta_out", "masked_predictions", "mask"):
+        assert torch.equal(out[k], again[k])                                 # run-to-run determinism
+        assert torch.isfinite(out[k]).all()
+    assert ((out["mask"] >= 0) & (out["mask"] <= 1)).all()
+    # linear masking: mask-in + mask-out resynthesis reconstructs the clip
+    assert (out["wave_in"] + out["wave_out"] - w).abs().max().item() < 2e-5
+    # a sub-batch gives bit-identical per-clip results (utterance independence => sharding is exact)
+    sub = pipe.explain(w[8:24].contiguous())
+    assert torch.equal(sub["theta_out"], out["theta_out"][8:24])
+    assert torch.equal(sub["predictions"], out["predictions"][8:24])

@@ -58,6 +58,9 @@ _lib = None
 def lib() -> C.CDLL:
     global _lib
     if _lib is None:
+        # torch first: it bundles its own libamdhip64; loading ours afterwards makes the dynamic linker
+        # reuse that runtime (same SONAME), so kernels and torch's device pointers share one HIP context.
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise AdvhError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                             "(there is no fallback path)")

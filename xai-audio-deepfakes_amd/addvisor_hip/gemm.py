@@ -38,6 +38,24 @@ class GemmDesc(C.Structure):
     ]
 
 
+class _Profile:
+    """Optional live timing of the dominant kernel (the 128x128 tile): HIP events recorded on the launch
+    stream around each launch; bench.py reads the totals after a synchronise."""
+
+    def __init__(self):
+        self.reset(False)
+
+    def reset(self, enabled: bool):
+        self.enabled, self.events = enabled, []
+
+    def summary(self):
+        ms = sum(a.elapsed_time(b) for a, b, _ in self.events)
+        return ms, sum(f for _, _, f in self.events), len(self.events)
+
+
+PROFILE = _Profile()
+
+
 def round_up(x: int, m: int) -> int:
     return (x + m - 1) // m * m
 
@@ -132,7 +150,14 @@ class GemmPlan:
             d.resid, d.resid_f32 = None, 0
         if stream is None:
             stream = torch.cuda.current_stream().cuda_stream
+        prof = PROFILE.enabled and self.tile == TILE_128x128
+        if prof:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         _lib.check(_lib.lib().advh_gemm_f16(C.byref(d), self.tile, stream), "advh_gemm_f16")
+        if prof:
+            e1.record()
+            PROFILE.events.append((e0, e1, self.flops))
 
 
 # ------------------------------------------------------------------------------------------ layouts

@@ -1,0 +1,100 @@
+"""One explanation per clip, end to end on the GPU (the unit of work of SURVEY.md §8d):
+
+    STFT -> classifier(clean) -> U-Net mask -> masked ISTFT (mask-in, mask-out) -> classifier x2
+         -> LMAC metric accumulators
+
+i.e. the loop body of ``run_addvisor_metrics`` (LMAC_metrics.py:117-157) with the D1-D5 resolutions of
+SURVEY.md §2.3.  Utterances are independent, so a data set shards over ranks by clip index with no
+data-path collective; the only exchange is one fixed-order gather of the per-clip probabilities
+(``gather_probabilities``), after which every rank reduces the same vector in the same order and
+obtains bit-identical metrics for any world size.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+
+from . import _lib, ops
+from .embedder import HipEmbedder
+from .synthetic import EmbedderConfig
+from .unet import HipUNet
+
+METRIC_NAMES = ("faithfulness", "fidelity", "AD", "AI", "AG")
+
+
+class ExplainPipeline:
+    def __init__(self, emb_cfg: EmbedderConfig, emb_sd, coef, intercept, unet_sd, device,
+                 audio_length: float = 4, sampling_rate: int = 16000, domain: str = "log1p",
+                 hop: int = 322, win: int = 644):
+        self.dev = device
+        self.L = int(audio_length * sampling_rate)
+        self.hop, self.win, self.domain = hop, win, domain
+        self.embedder = HipEmbedder(emb_cfg, emb_sd, coef, intercept, device)
+        self.unet = HipUNet(unet_sd, device)
+
+    def explain(self, waves: torch.Tensor, keep: bool = False) -> Dict[str, torch.Tensor]:
+        """``waves [B, n]`` fp32 on the GPU -> clean / mask-in / mask-out probabilities ``[B,1]`` and the mask."""
+        L = self.L
+        B = waves.shape[0]
+        _, mag, phase = ops.stft_forward(waves, L, self.hop, self.win, want_complex=False)
+        _, _, p_clean = self.embedder.forward(waves, L, want_hidden=False)
+        mask = self.unet.forward(mag)
+        both = torch.empty((2 * B, L), dtype=torch.float32, device=waves.device)
+        rc = _lib.lib().advh_istft_masked(
+            mag.data_ptr(), phase.data_ptr(), mask.data_ptr(), mask.shape[1], mask.shape[2],
+            {"linear": 1, "log1p": 2}[self.domain], both.data_ptr(), both[B:].data_ptr(), L, B, mag.shape[2], L,
+            self.hop, self.win, None, torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "advh_istft_masked")
+        _, _, p2 = self.embedder.forward(both, L, want_hidden=False)        # mask-in and mask-out as one 2B batch
+        out = dict(predictions=p_clean, theta_out=p2[:B], masked_predictions=p2[B:], mask=mask)
+        if keep:
+            out.update(mag=mag, phase=phase, wave_in=both[:B], wave_out=both[B:])
+        return out
+
+    def flops(self, B: int) -> float:
+        """Algorithmic FLOPs of one explain() call on B clips (3 embedder passes + U-Net)."""
+        T = 1 + self.L // self.hop
+        return 3.0 * self.embedder.flops(B, self.L) + self.unet.flops(B, 512, (T // 4) * 4)
+
+
+def lmac_metrics(predictions: torch.Tensor, theta_out: torch.Tensor, masked_predictions: torch.Tensor,
+                 per_clip: bool = False):
+    """The five dataset means of LMAC_metrics.py:164-172 from ``[N,1]`` (or ``[N]``) GPU probabilities."""
+    p = predictions.reshape(-1).contiguous().float()
+    t = theta_out.reshape(-1).contiguous().float()
+    o = masked_predictions.reshape(-1).contiguous().float()
+    n = p.numel()
+    if t.numel() != n or o.numel() != n or n == 0:
+        raise ValueError("need three probability vectors of equal, non-zero length")
+    sums = torch.empty(6, dtype=torch.float64, device=p.device)
+    pc = torch.empty((5, n), dtype=torch.float32, device=p.device) if per_clip else None
+    rc = _lib.lib().advh_lmac_metrics_accumulate(p.data_ptr(), t.data_ptr(), o.data_ptr(), n, sums.data_ptr(),
+                                                 None if pc is None else pc.data_ptr(),
+                                                 torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "advh_lmac_metrics_accumulate")
+    s = sums.cpu()
+    res = {k: float(s[i] / s[5]) for i, k in enumerate(METRIC_NAMES)}
+    return (res, pc) if per_clip else res
+
+
+# ------------------------------------------------------------------------------------------ sharding
+def shard_indices(n_total: int, rank: int, world: int) -> range:
+    """Contiguous block partition of clip indices: rank r owns [r*ceil(N/W), ...)."""
+    per = -(-n_total // world)
+    return range(min(rank * per, n_total), min((rank + 1) * per, n_total))
+
+
+def gather_probabilities(local: torch.Tensor, n_total: int, group=None) -> torch.Tensor:
+    """``local [n_r, 3]`` (p, theta, p_out of this rank's block) -> ``[n_total, 3]`` in clip order on every
+    rank.  One all_gather of equal-sized, zero-padded blocks (RCCL on GPUs, gloo in the CPU tests)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return local
+    world = dist.get_world_size(group)
+    per = -(-n_total // world)
+    pad = torch.zeros((per, 3), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad, group=group)
+    return torch.cat(parts, 0)[:n_total]
