@@ -124,9 +124,11 @@ int advh_gemm_f16(const advh_gemm_desc* desc, int tile, advh_stream_t stream);
  * wave [B][wave_stride] fp32 (n_in valid samples, padded / cropped to L);  w0 [C0][10] fp32.
  * mode 0 ("group"): out = GELU(GroupNorm(conv)), gamma/beta [C0];  mode 1 ("layer"): out = conv + bias0.
  * out: fp16 channels-last [B][P0][C0], rows t in [T0,P0) written as zeros; T0 = (L-10)/5 + 1.
+ * normalize: 1 = apply zero_mean_unit_var_norm first; 0 = wave is already normalised (the raw
+ *   `wav2vec2(input_values)` call of audioprocessor.py:76).
  * stats_ws: [B][2] fp32 workspace (clip mean, 1/(std+1e-7));  norm_ws: [B][C0][2] fp32 (mode 0).   */
 int advh_w2v2_frontend(const float* wave, int64_t wave_stride, int n_in, int B, int L, const float* w0,
-                       const float* bias0, const float* gamma, const float* beta, int mode, float* stats_ws,
+                       const float* bias0, const float* gamma, const float* beta, int mode, int normalize, float* stats_ws,
                        float* norm_ws, void* out, int T0, int P0, int C0, advh_stream_t stream);
 
 /* LayerNorm over the last dimension (+ optional GELU): nn.LayerNorm call sites of

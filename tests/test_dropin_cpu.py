@@ -1,0 +1,107 @@
+"""CPU-only: host logic of the drop-in modules and of the utterance sharding (gloo, world_size 2)."""
+import inspect
+import os
+import struct
+import wave
+
+import numpy as np
+import pytest
+import torch
+
+from addvisor_hip import pipeline as P, synthetic as syn
+
+
+def test_modules_import_without_gpu_or_network():
+    from addvisor_hip import runtime
+    os.environ.pop("ADDVISOR_EMBEDDER", None)
+    runtime.reset()
+    import addvisor
+    import audioprocessor
+    import classifier_embedder
+    import LMAC_metrics
+    import loss_function
+    assert addvisor.ADDvisor is addvisor.UNet
+    sig = inspect.signature(audioprocessor.AudioProcessor.__init__)
+    assert [p for p in sig.parameters][1:] == ["sampling_rate", "n_fft", "hop_length", "win_length", "n_mels", "audio_length"]
+    d = {k: v.default for k, v in sig.parameters.items() if k != "self"}
+    assert d == dict(sampling_rate=16000, n_fft=1024, hop_length=322, win_length=644, n_mels=80, audio_length=5)
+    for name in ("compute_fidelity", "get_score_for_predicted_class", "compute_faithfulness", "compute_AD",
+                 "compute_AI", "compute_AG", "extract_wavs", "AudioDataset", "collate_fn", "run_addvisor_metrics"):
+        assert hasattr(LMAC_metrics, name)
+    lm = loss_function.LMACLoss()
+    assert lm.w_raw.tolist() == [3.0, 0.5, 3.0] and torch.allclose(lm.w, torch.nn.functional.softplus(lm.w_raw))
+    clf = classifier_embedder.classifier
+    assert clf.coef_.shape == (1, 768) and clf.intercept_.shape == (1,)
+
+
+def test_unet_state_dict_layout():
+    import addvisor
+    u = addvisor.UNet()
+    ref = syn.unet_weights()
+    assert set(u.state_dict().keys()) == set(ref.keys())
+    for k, v in u.state_dict().items():
+        assert tuple(v.shape) == tuple(ref[k].shape), k
+    u.load_state_dict({"module." + k: v for k, v in ref.items()})       # DDP prefix (LMAC_metrics.py:23-25)
+    assert torch.equal(u.state_dict()["e1.block.0.weight"], ref["e1.block.0.weight"])
+
+
+def test_load_audio_and_metadata(tmp_path):
+    import audioprocessor
+    import LMAC_metrics
+    x = (np.sin(np.arange(8000) / 10.0) * 20000).astype("<i2")
+    p = tmp_path / "a.wav"
+    with wave.open(str(p), "wb") as w:
+        w.setnchannels(1), w.setsampwidth(2), w.setframerate(16000)
+        w.writeframes(x.tobytes())
+    ap = audioprocessor.AudioProcessor(audio_length=1)
+    a, sr = ap.load_audio(str(p))
+    assert sr == 16000 and a.shape == (16000,) and a.dtype == torch.float32
+    assert torch.allclose(a[:8000], torch.from_numpy(x.astype(np.float32) / 32768.0)) and (a[8000:] == 0).all()
+    a2, _ = audioprocessor.AudioProcessor(audio_length=0.25).load_audio(str(p))
+    assert a2.shape == (4000,)
+    meta = tmp_path / "meta.txt"
+    meta.write_text("x/a.wav,1,foo\ny/b.wav,0\n")
+    assert LMAC_metrics.extract_wavs(str(meta)) == ["x/a.wav", "y/b.wav"]
+
+
+def test_stft_argument_errors():
+    import audioprocessor
+    ap = audioprocessor.AudioProcessor(audio_length=1)
+    with pytest.raises(ValueError, match="waveform must be 1D"):
+        ap.compute_stft(torch.zeros(2, 3, 16000))
+    with pytest.raises(ValueError, match="ISTFT expects complex input!"):
+        ap.compute_invert_stft(torch.zeros(1, 513, 50))
+
+
+def test_shard_indices_cover_and_are_disjoint():
+    for n, w in ((71237, 8), (10, 4), (3, 8), (64, 1)):
+        seen = []
+        for r in range(w):
+            seen += list(P.shard_indices(n, r, w))
+        assert seen == list(range(n))
+
+
+def _worker(rank, world, n_total, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    full = torch.from_numpy(np.random.Generator(np.random.PCG64(5)).uniform(0, 1, size=(n_total, 3)).astype(np.float32))
+    idx = P.shard_indices(n_total, rank, world)
+    got = P.gather_probabilities(full[idx.start:idx.stop].clone(), n_total)
+    q.put((rank, torch.equal(got, full)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_total", [37, 64])
+def test_gather_probabilities_gloo_world2(n_total):
+    """The one exchange step of the sharded run: every rank ends with the same [N,3] table in clip order,
+    so the metric reduction is bit-identical to the 1-rank run."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000) + n_total
+    procs = [ctx.Process(target=_worker, args=(r, 2, n_total, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = [q.get(timeout=120) for _ in procs]
+    [p.join(60) for p in procs]
+    assert all(ok for _, ok in res) and all(p.exitcode == 0 for p in procs)

@@ -1,0 +1,83 @@
+"""Drop-in for the reference's ``addvisor`` module (addvisor.py:1-84): ``ConvBlock`` / ``UNet`` with the
+reference's parameter names (so checkpoints load with ``load_state_dict``), forward on the HIP
+implicit-GEMM kernels.  ``ADDvisor`` is the name LMAC_metrics.py:6 imports."""
+import warnings
+
+import torch
+import torch.nn as nn
+
+from audioprocessor import AudioProcessor
+
+audio_processor = AudioProcessor()
+
+
+class ConvBlock(nn.Module):
+    """addvisor.py:12-25 -- parameter container; the arithmetic runs inside ``UNet.forward``."""
+
+    def __init__(self, in_ch, out_ch, kernel_size=(3, 3), stride=(1, 1), padding=(1, 1)):
+        super().__init__()
+        self.block = nn.Sequential(
+            nn.Conv2d(in_ch, out_ch, kernel_size, stride=stride, padding=padding),
+            nn.BatchNorm2d(out_ch),
+            nn.LeakyReLU(0.2, inplace=True),
+            nn.Conv2d(out_ch, out_ch, kernel_size=3, padding=1),
+            nn.BatchNorm2d(out_ch),
+            nn.LeakyReLU(0.2, inplace=True),
+        )
+
+    def forward(self, x):
+        raise RuntimeError("ConvBlock is executed as part of UNet.forward on the HIP path")
+
+
+class UNet(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.e1 = ConvBlock(1, 32, kernel_size=(5, 3), stride=(2, 1), padding=(2, 1))
+        self.e2 = ConvBlock(32, 64, kernel_size=(5, 3), stride=(2, 1), padding=(2, 1))
+        self.e3 = ConvBlock(64, 128, stride=(2, 2))
+        self.e4 = ConvBlock(128, 256, stride=(2, 2))
+        self.bottleneck = nn.Sequential(
+            nn.Conv2d(256, 512, kernel_size=3, padding=2, dilation=2), nn.BatchNorm2d(512), nn.LeakyReLU(0.2, inplace=True),
+            nn.Conv2d(512, 512, kernel_size=3, padding=4, dilation=4), nn.BatchNorm2d(512), nn.LeakyReLU(0.2, inplace=True))
+        self.up4 = nn.ConvTranspose2d(512, 256, kernel_size=(2, 2), stride=(2, 2))
+        self.d4 = ConvBlock(384, 256)
+        self.up3 = nn.ConvTranspose2d(256, 128, kernel_size=(2, 2), stride=(2, 2))
+        self.d3 = ConvBlock(192, 128)
+        self.up2 = nn.ConvTranspose2d(128, 64, kernel_size=(2, 1), stride=(2, 1))
+        self.d2 = ConvBlock(96, 64)
+        self.up1 = nn.ConvTranspose2d(64, 32, kernel_size=(2, 1), stride=(2, 1))
+        self.d1 = ConvBlock(33, 32)
+        self.mask_head = nn.Sequential(nn.Conv2d(32, 1, kernel_size=1), nn.Sigmoid())
+        self._hip = None
+        self._warned = False
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        state_dict = {k.replace("module.", "", 1) if k.startswith("module.") else k: v for k, v in state_dict.items()}
+        self._hip = None                                   # repack the fp16 weights on next forward
+        return super().load_state_dict(state_dict, strict=strict, **kw)
+
+    def _engine(self, dev):
+        if self._hip is None:
+            from addvisor_hip.unet import HipUNet
+            self._hip = HipUNet({k: v.detach().cpu() for k, v in self.state_dict().items()}, dev)
+        return self._hip
+
+    def forward(self, x):
+        """``x [B,1,F,T]`` (or ``[B,F,T]``) magnitude, F % 16 == 0 and T % 4 == 0 -> mask, same shape."""
+        if self.training and not self._warned:
+            warnings.warn("UNet is in training mode; the HIP path always uses eval-mode BatchNorm "
+                          "(running statistics), see SURVEY.md D5", stacklevel=2)
+            self._warned = True
+        squeeze = x.dim() == 3
+        x4 = x[:, None] if squeeze else x
+        if x4.dim() != 4 or x4.shape[1] != 1:
+            raise ValueError("expected [B,1,F,T]")
+        B, _, Fq, Tq = x4.shape
+        if Fq % 16 or Tq % 4:
+            raise RuntimeError(f"U-Net skip connections need F % 16 == 0 and T % 4 == 0, got {Fq}x{Tq}")
+        dev = torch.device("cuda")
+        mask = self._engine(dev).forward(x4[:, 0].to(dev, torch.float32).contiguous(), H=Fq, W=Tq)
+        return mask if squeeze else mask[:, None]
+
+
+ADDvisor = UNet

@@ -41,7 +41,7 @@ SIGNATURES = {
     "advh_istft_masked": (_i, [_p, _p, _p, _i, _i, _i, _p, _p, _i64, _i, _i, _i, _i, _i, _p, _p]),
     "advh_istft_c64": (_i, [_p, _p, _i64, _i, _i, _i, _i, _i, _p, _p]),
     "advh_gemm_f16": (_i, [_p, _i, _p]),
-    "advh_w2v2_frontend": (_i, [_p, _i64, _i, _i, _i, _p, _p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _p]),
+    "advh_w2v2_frontend": (_i, [_p, _i64, _i, _i, _i, _p, _p, _p, _p, _i, _i, _p, _p, _p, _i, _i, _i, _p]),
     "advh_layernorm": (_i, [_p, _i, _i64, _p, _p, _p, _p, _i64, _i, _i, _f, _i, _p]),
     "advh_posconv_gather": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
     "advh_attention_f16": (_i, [_p, _p, _i, _i, _i, _i, _p]),

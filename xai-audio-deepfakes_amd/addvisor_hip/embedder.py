@@ -161,7 +161,8 @@ class HipEmbedder:
         return self._workspace(B, L)["flops"]
 
     # ------------------------------------------------------------------ forward
-    def forward(self, wave: torch.Tensor, length: Optional[int] = None, want_hidden: bool = True):
+    def forward(self, wave: torch.Tensor, length: Optional[int] = None, want_hidden: bool = True,
+                normalize: bool = True):
         """Returns ``(hidden [B,T,H] fp32 or None, logits [B,1], probs [B,1])`` -- fresh tensors."""
         if wave.dim() != 2 or wave.dtype != torch.float32 or not wave.is_cuda:
             raise ValueError("wave must be a CUDA fp32 tensor [B, n]")
@@ -179,7 +180,7 @@ class HipEmbedder:
         ln0 = self.fe_ln[0]
         _lib.check(lib.advh_w2v2_frontend(
             wave.data_ptr(), wave.stride(0), n_in, B, L, self.w0.data_ptr(),
-            None if self.b0 is None else self.b0.data_ptr(), ln0.g.data_ptr(), ln0.b.data_ptr(), mode,
+            None if self.b0 is None else self.b0.data_ptr(), ln0.g.data_ptr(), ln0.b.data_ptr(), mode, int(normalize),
             ws["stats"].data_ptr(), ws["norm"].data_ptr(), a.data_ptr(), Ls[0], P[0], C[0], st), "advh_w2v2_frontend")
         if self.layer_mode:
             ln0(a, B * P[0], 1e-5, out_h=a, gelu=True)

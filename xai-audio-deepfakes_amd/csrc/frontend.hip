@@ -32,8 +32,12 @@ __device__ __forceinline__ double block_sum_d(double v, double* red) {
 
 // stats[b] = (mean, 1/(std_unbiased + 1e-7)) of the clip padded / cropped to L samples
 __global__ __launch_bounds__(256) void wave_stats_kernel(const float* __restrict__ wave, long stride, int n_in, int L,
-                                                         float2* __restrict__ stats) {
+                                                         float2* __restrict__ stats, int normalize) {
     __shared__ double red[4];
+    if (!normalize) {                                  // input_values already normalised by the caller
+        if (threadIdx.x == 0) stats[blockIdx.x] = make_float2(0.f, 1.f);
+        return;
+    }
     const float* w = wave + (long)blockIdx.x * stride;
     const int n = n_in < L ? n_in : L;
     double s = 0;
@@ -157,14 +161,14 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ wa
 using namespace advh;
 
 extern "C" int advh_w2v2_frontend(const float* wave, int64_t wave_stride, int n_in, int B, int L, const float* w0,
-                                  const float* bias0, const float* gamma, const float* beta, int mode, float* stats_ws,
+                                  const float* bias0, const float* gamma, const float* beta, int mode, int normalize, float* stats_ws,
                                   float* norm_ws, void* out, int T0, int P0, int C0, advh_stream_t stream) {
     if (!wave || !w0 || !stats_ws || !out || B <= 0 || L < K0 || n_in <= 0 || C0 <= 0 || C0 > 512 || (C0 & 1)) return ADVH_EINVAL;
     if (T0 != (L - K0) / S0 + 1 || P0 < T0 || wave_stride < (n_in < L ? n_in : L)) return ADVH_EINVAL;
     if (mode == 0 && (!gamma || !beta || !norm_ws)) return ADVH_EINVAL;
     if (mode != 0 && mode != 1) return ADVH_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(wave_stats_kernel, dim3(B), dim3(256), 0, s, wave, (long)wave_stride, n_in, L, (float2*)stats_ws);
+    hipLaunchKernelGGL(wave_stats_kernel, dim3(B), dim3(256), 0, s, wave, (long)wave_stride, n_in, L, (float2*)stats_ws, normalize);
     if (mode == 0)
         hipLaunchKernelGGL(gn_stats_kernel, dim3(B), dim3(256), 0, s, wave, (long)wave_stride, n_in, L,
                            (const float2*)stats_ws, w0, gamma, beta, (float2*)norm_ws, T0, C0);

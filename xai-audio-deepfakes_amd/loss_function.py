@@ -1,0 +1,44 @@
+"""Drop-in for the reference's ``loss_function`` module (loss_function.py:1-77): LMAC loss forward on the
+HIP path.  Gradients flow to ``w_raw``; the backward through the frozen embedder / ISTFT to the mask
+is SURVEY.md §8(f) rank 1 (not built yet), so ``total_loss`` is not differentiable w.r.t. ``xhat``."""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from addvisor_hip import ops as _ops, runtime as _rt
+from audioprocessor import AudioProcessor
+from classifier_embedder import TorchLogReg
+
+device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+audio_processor = AudioProcessor()
+
+
+class LMACLoss(nn.Module):
+    def __init__(self, reg_w_tv=0.00):
+        super().__init__()
+        self.reg_w_tv = reg_w_tv
+        self.w_raw = nn.Parameter(torch.tensor([3.0, 0.5, 3.0], requires_grad=True))     # loss_function.py:24
+
+    @property
+    def w(self):
+        return F.softplus(self.w_raw)
+
+    def loss_function(self, xhat, X_stft_power, X_stft_phase, class_pred):
+        """loss_function.py:32-66.  ``xhat [B,1,F',T']`` is embedded into the 513 x T grid with zeros
+        outside; linear masking; two resyntheses; two classifier passes."""
+        ap = audio_processor
+        L = int(ap.audio_length * ap.sampling_rate)
+        m = xhat.squeeze(1).to(device, torch.float32).contiguous()
+        mag = X_stft_power.to(device, torch.float32).contiguous()
+        ph = X_stft_phase.to(device, torch.float32).contiguous()
+        w_in, w_out = _ops.istft_masked(mag, ph, m.detach(), L, domain="linear", hop=ap.hop_length, win=ap.win_length)
+        emb = _rt.hip_embedder()
+        _, l_rel, _ = emb.forward(w_in, L, want_hidden=False)
+        _, l_irr, _ = emb.forward(w_out, L, want_hidden=False)
+        cp = class_pred.to(device, torch.float32)
+        l_in = F.binary_cross_entropy_with_logits(l_rel, cp)
+        l_out = F.binary_cross_entropy_with_logits(l_irr, 1 - cp)
+        reg_l1 = m.abs().mean()
+        losses = torch.stack([l_in, l_out, reg_l1])
+        w = self.w.to(device)
+        return torch.sum(w * losses), losses, self.w
