@@ -92,7 +92,8 @@ int advh_istft_c64(const float* spec, float* wave, int64_t wave_stride, int B, i
  * (n_div % 4 == 0; every term a multiple of 4 elements).  `nz` batches (grid z) advance the
  * operands by a_sZ (chunks), w_sZ (elements), bias_sZ, o_sZ.                                     */
 enum { ADVH_ACT_NONE = 0, ADVH_ACT_GELU = 1, ADVH_ACT_LEAKY = 2 };
-enum { ADVH_TILE_AUTO = 0, ADVH_TILE_128x128 = 1, ADVH_TILE_256x64 = 2, ADVH_TILE_256x32 = 3 };
+enum { ADVH_TILE_AUTO = 0, ADVH_TILE_128x128 = 1, ADVH_TILE_256x64 = 2, ADVH_TILE_256x32 = 3,
+       ADVH_TILE_256x256 = 4, ADVH_TILE_256x128 = 5 /* 512-thread, 2-stage LDS ring */ };
 
 typedef struct advh_gemm_desc {
     const void* A0;       /* fp16 source 0                                   */

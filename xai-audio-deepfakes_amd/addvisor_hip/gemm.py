@@ -18,7 +18,9 @@ from . import _lib
 
 BK = 64
 ACT = {"none": 0, "gelu": 1, "leaky": 2}
-TILE_AUTO, TILE_128x128, TILE_256x64, TILE_256x32 = 0, 1, 2, 3
+TILE_AUTO, TILE_128x128, TILE_256x64, TILE_256x32, TILE_256x256, TILE_256x128 = 0, 1, 2, 3, 4, 5
+TILE_BN = {TILE_128x128: 128, TILE_256x64: 64, TILE_256x32: 32, TILE_256x256: 256, TILE_256x128: 128}
+TILE_NAMES = {TILE_128x128: "128x128", TILE_256x64: "256x64", TILE_256x32: "256x32", TILE_256x256: "256x256p", TILE_256x128: "256x128p"}
 
 
 class GemmDesc(C.Structure):
@@ -94,7 +96,7 @@ class GemmPlan:
         assert K == 8 * len(ktab), (K, len(ktab))
         Kp = round_up(K, BK)
         tile, BN = pick_tile(N)
-        w_rows = round_up(N, BN)
+        w_rows = round_up(N, 256)        # any tile's BN divides 256: the tile can be re-chosen later (autotune)
         wp = torch.zeros((nz, w_rows, Kp), dtype=torch.float16)
         wp[:, :N, :K] = w2.to(torch.float16)
         kt = np.concatenate([ktab, np.full((Kp - K) // 8, ktab[0], dtype=np.int64)]).astype(np.int64)

@@ -14,6 +14,7 @@
 #include <hip/hip_fp16.h>
 #include "addvisor_hip.h"
 #include "common.h"
+#include "device_math.h"
 
 namespace advh {
 
@@ -147,8 +148,8 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ wa
             for (int k = 0; k < K0; ++k) { float x = xs[S0 * t + k]; ya = fmaf(wa[k], x, ya); yb = fmaf(wb[k], x, yb); }
             ya = ya * sa + ha; yb = yb * sb + hb;
             if (mode == 0) {
-                ya = 0.5f * ya * (1.f + erff(ya * 0.70710678118654752440f));
-                yb = 0.5f * yb * (1.f + erff(yb * 0.70710678118654752440f));
+                ya = gelu_fast(ya);
+                yb = gelu_fast(yb);
             }
         }
         __half2 h = __floats2half2_rn(ya, yb);

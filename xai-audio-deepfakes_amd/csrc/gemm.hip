@@ -22,6 +22,7 @@
 #include <hip/hip_fp16.h>
 #include "addvisor_hip.h"
 #include "common.h"
+#include "device_math.h"
 
 namespace advh {
 
@@ -35,9 +36,76 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int BK = 64;          // halfs per K-step = 8 chunks of 16 B
 
 __device__ __forceinline__ float apply_act(float x, int act, float slope) {
-    if (act == ADVH_ACT_GELU) return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f));
+    if (act == ADVH_ACT_GELU) return gelu_fast(x);
     if (act == ADVH_ACT_LEAKY) return x > 0.f ? x : slope * x;
     return x;
+}
+
+// m -> (b, h, w) with m = (b*Hg + h)*Wg + w, without integer division: double-precision reciprocal
+// multiply + one correction step (exact for m, d < 2^31).
+struct RowDecomp {
+    double iw, ih;
+    unsigned Wg, Hg;
+    __device__ __forceinline__ RowDecomp(unsigned Wg_, unsigned Hg_) : iw(1.0 / Wg_), ih(1.0 / Hg_), Wg(Wg_), Hg(Hg_) {}
+    __device__ __forceinline__ static unsigned divq(unsigned n, unsigned d, double inv) {
+        unsigned q = (unsigned)((double)n * inv);
+        long r = (long)n - (long)q * d;
+        if (r < 0) --q; else if (r >= (long)d) ++q;
+        return q;
+    }
+    __device__ __forceinline__ void operator()(unsigned m, unsigned& b, unsigned& h, unsigned& w) const {
+        unsigned t = divq(m, Wg, iw);
+        w = m - t * Wg;
+        if (Hg == 1) { h = 0; b = t; }
+        else { b = divq(t, Hg, ih); h = t - b * Hg; }
+    }
+};
+
+// Epilogue shared by the GEMM kernels: lane (fr = lane & 15, fq = lane >> 4) holds, per (ni, mi), output
+// channels n .. n+3 of row m (W is the MFMA A operand).  bias + activation + residual + fp16 / fp32 stores.
+template <int MI, int NI>
+__device__ __forceinline__ void gemm_epilogue(const advh_gemm_desc& p, f32x4 (&acc)[NI][MI], int mw0, int nw0, int fr, int fq, int z) {
+    const float* bias = p.bias ? p.bias + (long)p.bias_sZ * z : nullptr;
+    const RowDecomp rd(p.Wg, p.Hg);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        unsigned m = mw0 + mi * 16 + fr;
+        if (m >= (unsigned)p.M) continue;
+        unsigned w, h, b;
+        rd(m, b, h, w);
+        bool ok = (int)h >= p.h0 && (int)h < p.h1 && (int)w >= p.w0 && (int)w < p.w1;
+        if (!ok && !p.halo_zero) continue;
+        long orow = (long)b * p.o_sB + (long)h * p.o_sH + (long)w * p.o_sW + p.o_c0 + p.o_sZ * z;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            int n = nw0 + ni * 16 + fq * 4;
+            if (n >= p.N) continue;
+            long o = orow + (long)(n / p.n_div) * p.o_sNhi + (n % p.n_div);
+            f32x4 v = acc[ni][mi];
+            if (ok) {
+                if (bias) { float4 bb = *(const float4*)(bias + n); v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w; }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], p.act, p.slope);
+                if (p.resid) {
+                    if (p.resid_f32) {
+                        float4 rr = *(const float4*)((const float*)p.resid + o);
+                        v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
+                    } else {
+                        f16x4 rr = *(const f16x4*)((const _Float16*)p.resid + o);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
+                    }
+                }
+            } else {
+                v = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            if (p.out_f) *(float4*)((float*)p.out_f + o) = make_float4(v[0], v[1], v[2], v[3]);
+            if (p.out_h) {
+                f16x4 hv = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+                *(f16x4*)((_Float16*)p.out_h + o) = hv;
+            }
+        }
+    }
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -75,11 +143,12 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(const advh_gemm_desc p) {
     long safe0 = (long)p.h0 * p.a_sH[0] + (long)p.w0 * p.a_sW[0] + p.a_c0[0];
     long safe1 = (long)p.h0 * p.a_sH[1] + (long)p.w0 * p.a_sW[1] + p.a_c0[1];
     unsigned rb0[NA], rb1[NA];
+    const RowDecomp rd(p.Wg, p.Hg);
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
         unsigned m = m0 + ldrow + 32 * i;
-        unsigned w = m % (unsigned)p.Wg, t = m / (unsigned)p.Wg;
-        unsigned h = t % (unsigned)p.Hg, b = t / (unsigned)p.Hg;
+        unsigned w, h, b;
+        rd(m, b, h, w);
         bool ok = m < (unsigned)p.M && (int)h >= p.h0 && (int)h < p.h1 && (int)w >= p.w0 && (int)w < p.w1;
         long r0 = ok ? (long)b * p.a_sB[0] + (long)h * p.a_sH[0] + (long)w * p.a_sW[0] + p.a_c0[0] : safe0;
         long r1 = ok ? (long)b * p.a_sB[1] + (long)h * p.a_sH[1] + (long)w * p.a_sW[1] + p.a_c0[1] : safe1;
@@ -142,47 +211,7 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(const advh_gemm_desc p) {
         __syncthreads();
     }
 
-    // ---- epilogue: lane holds, per (ni, mi), channels n..n+3 of row m
-    const float* bias = p.bias ? p.bias + (long)p.bias_sZ * z : nullptr;
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-        unsigned m = m0 + wm * TM + mi * 16 + fr;
-        if (m >= (unsigned)p.M) continue;
-        unsigned w = m % (unsigned)p.Wg, t = m / (unsigned)p.Wg;
-        unsigned h = t % (unsigned)p.Hg, b = t / (unsigned)p.Hg;
-        bool ok = (int)h >= p.h0 && (int)h < p.h1 && (int)w >= p.w0 && (int)w < p.w1;
-        if (!ok && !p.halo_zero) continue;
-        long orow = (long)b * p.o_sB + (long)h * p.o_sH + (long)w * p.o_sW + p.o_c0 + p.o_sZ * z;
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-            int n = n0 + wn * TN + ni * 16 + fq * 4;
-            if (n >= p.N) continue;
-            long o = orow + (long)(n / p.n_div) * p.o_sNhi + (n % p.n_div);
-            f32x4 v = acc[ni][mi];
-            if (ok) {
-                if (bias) { float4 bb = *(const float4*)(bias + n); v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w; }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], p.act, p.slope);
-                if (p.resid) {
-                    if (p.resid_f32) {
-                        float4 rr = *(const float4*)((const float*)p.resid + o);
-                        v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
-                    } else {
-                        f16x4 rr = *(const f16x4*)((const _Float16*)p.resid + o);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
-                    }
-                }
-            } else {
-                v = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-            if (p.out_f) *(float4*)((float*)p.out_f + o) = make_float4(v[0], v[1], v[2], v[3]);
-            if (p.out_h) {
-                f16x4 hv = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
-                *(f16x4*)((_Float16*)p.out_h + o) = hv;
-            }
-        }
-    }
+    gemm_epilogue<MI, NI>(p, acc, m0 + wm * TM, n0 + wn * TN, fr, fq, z);
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -194,11 +223,135 @@ static int launch(const advh_gemm_desc& d, hipStream_t s) {
     return ADVH_LAUNCH_CHECK();
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Large-tile variant: 512 threads = 8 wavefronts (2 per SIMD), BM x BN x 64 tile with a 2-stage LDS ring
+// (dynamic LDS, up to 128 KiB => one workgroup per CU).  The global->LDS DMA of K-tile t+1 is issued
+// right after the barrier that publishes K-tile t and stays in flight under the 64 MFMAs per wavefront of
+// tile t; one barrier per K-step.  Wave tile (BM/WM) x (BN/WN) = 128 x 64 for 256 x 256: 24 ds_read_b128
+// feed 64 MFMAs (the 128 x 128 kernel needs 16 per 32), which is what lifts the LDS-read bound.
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(512) void gemm_f16_pipe_kernel(const advh_gemm_desc p) {
+    constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 16, NI = TN / 16;
+    constexpr int NA = BM / 64, NB = BN / 64;      // 16-byte chunks per thread per K-step (512 threads)
+    constexpr int STAGE = (BM + BN) * BK * 2;
+    static_assert(WM * WN == 8, "8 wavefronts");
+    extern __shared__ __attribute__((aligned(16))) char dsmem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wm = wv / WN, wn = wv % WN;
+    const int tilesN = (p.N + BN - 1) / BN;
+    const int nwg = gridDim.x;
+    int id = blockIdx.x;
+    {
+        const int q8 = nwg / 8, r8 = nwg % 8, xcd = id % 8;
+        id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + id / 8;
+    }
+    const int tile_n = id % tilesN, tile_m = id / tilesN;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int z = blockIdx.z;
+    const _Float16* A0 = (const _Float16*)p.A0 + p.a_sZ[0] * z * 8;
+    const _Float16* A1 = (const _Float16*)p.A1 + p.a_sZ[1] * z * 8;
+    const _Float16* Wp = (const _Float16*)p.W + p.w_sZ * z;
+
+    const int ldrow = tid >> 3;                          // + 64*i
+    const int q = (tid & 7) ^ (ldrow & 7);
+    long safe0 = (long)p.h0 * p.a_sH[0] + (long)p.w0 * p.a_sW[0] + p.a_c0[0];
+    long safe1 = (long)p.h0 * p.a_sH[1] + (long)p.w0 * p.a_sW[1] + p.a_c0[1];
+    unsigned rb0[NA], rb1[NA];
+    const RowDecomp rd(p.Wg, p.Hg);
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        unsigned m = m0 + ldrow + 64 * i;
+        unsigned w, h, b;
+        rd(m, b, h, w);
+        bool ok = m < (unsigned)p.M && (int)h >= p.h0 && (int)h < p.h1 && (int)w >= p.w0 && (int)w < p.w1;
+        long r0 = ok ? (long)b * p.a_sB[0] + (long)h * p.a_sH[0] + (long)w * p.a_sW[0] + p.a_c0[0] : safe0;
+        long r1 = ok ? (long)b * p.a_sB[1] + (long)h * p.a_sH[1] + (long)w * p.a_sW[1] + p.a_c0[1] : safe1;
+        rb0[i] = (unsigned)r0;
+        rb1[i] = (unsigned)r1;
+    }
+    const _Float16* wrow[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) wrow[i] = Wp + (long)(n0 + ldrow + 64 * i) * p.Ktot + q * 8;
+
+    const int fr = lane & 15, fq = lane >> 4;
+    int offA[2], offB[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        int c = (kk * 4 + fq) ^ (fr & 7);
+        offA[kk] = ((wm * TM + fr) * 8 + c) * 16;
+        offB[kk] = BM * BK * 2 + ((wn * TN + fr) * 8 + c) * 16;
+    }
+
+    f32x4 acc[NI][MI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.Ktot / BK;
+    auto issue = [&](int kt, int kq) {
+        char* st = dsmem + (kt & 1) * STAGE;
+        const bool s1 = kq < 0;
+        const unsigned ko = (unsigned)kq & 0x7fffffffu;
+        const _Float16* base = s1 ? A1 : A0;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const _Float16* g = base + ((unsigned long)((s1 ? rb1[i] : rb0[i]) + ko)) * 8;
+            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(g), LDS_PTR(st + (wv * 64 + 512 * i) * 16), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(wrow[i] + kt * BK),
+                                             LDS_PTR(st + BM * BK * 2 + (wv * 64 + 512 * i) * 16), 16, 0, 0);
+    };
+    int kq = p.ktab[q];
+    issue(0, kq);
+    if (nk > 1) kq = p.ktab[8 + q];
+    for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // tile kt (and the ktab prefetch) landed
+        __builtin_amdgcn_s_barrier();                          // ... for every wavefront; stage (kt+1)&1 is free
+        if (kt + 1 < nk) {
+            issue(kt + 1, kq);                                 // in flight under the MFMAs below
+            if (kt + 2 < nk) kq = p.ktab[(kt + 2) * 8 + q];
+        }
+        const char* st = dsmem + (kt & 1) * STAGE;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            f16x8 a[MI], b[NI];
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) b[ni] = *(const f16x8*)(st + offB[kk] + ni * 16 * 128);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) a[mi] = *(const f16x8*)(st + offA[kk] + mi * 16 * 128);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[ni], a[mi], acc[ni][mi], 0, 0, 0);
+        }
+    }
+    gemm_epilogue<MI, NI>(p, acc, m0 + wm * TM, n0 + wn * TN, fr, fq, z);
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch_pipe(const advh_gemm_desc& d, hipStream_t s) {
+    const int tilesM = (d.M + BM - 1) / BM, tilesN = (d.N + BN - 1) / BN;
+    if (tilesN * BN > d.w_rows) return ADVH_EINVAL;
+    dim3 grid(tilesM * tilesN, 1, d.nz > 0 ? d.nz : 1);
+    hipLaunchKernelGGL((gemm_f16_pipe_kernel<BM, BN, WM, WN>), grid, dim3(512), 2 * (BM + BN) * BK * 2, s, d);
+    return ADVH_LAUNCH_CHECK();
+}
+
 }  // namespace advh
 
 using namespace advh;
 
-int advh_init_rest() { return ADVH_OK; }
+int advh_init_rest() {
+    const int maxlds = 160 * 1024;
+    if (hipFuncSetAttribute((const void*)gemm_f16_pipe_kernel<256, 256, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, maxlds) != hipSuccess) return ADVH_ELAUNCH;
+    if (hipFuncSetAttribute((const void*)gemm_f16_pipe_kernel<256, 128, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, maxlds) != hipSuccess) return ADVH_ELAUNCH;
+    return ADVH_OK;
+}
 
 extern "C" int advh_gemm_f16(const advh_gemm_desc* d, int tile, advh_stream_t stream) {
     if (!d || !d->A0 || !d->W || !d->ktab || (!d->out_h && !d->out_f)) return ADVH_EINVAL;
@@ -212,6 +365,8 @@ extern "C" int advh_gemm_f16(const advh_gemm_desc* d, int tile, advh_stream_t st
         case ADVH_TILE_128x128: return launch<128, 128, 2, 2>(*d, s);
         case ADVH_TILE_256x64: return launch<256, 64, 4, 1>(*d, s);
         case ADVH_TILE_256x32: return launch<256, 32, 4, 1>(*d, s);
+        case ADVH_TILE_256x256: return launch_pipe<256, 256, 2, 4>(*d, s);
+        case ADVH_TILE_256x128: return launch_pipe<256, 128, 4, 2>(*d, s);
         default: return ADVH_EINVAL;
     }
 }

@@ -5,6 +5,7 @@
 #include <hip/hip_fp16.h>
 #include "addvisor_hip.h"
 #include "common.h"
+#include "device_math.h"
 
 namespace advh {
 
@@ -16,7 +17,6 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
 
 // LayerNorm over the last dim C (C % 4 == 0, C <= 64*4*MAXV): torch.nn.functional.layer_norm semantics
 // (biased variance, eps inside the sqrt); two-pass in registers for accuracy.
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const void* __restrict__
                           (v[i][2] - mean) * rstd * g.z + b.z, (v[i][3] - mean) * rstd * g.w + b.w};
             if (gelu) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = gelu_erf(o[r]);
+                for (int r = 0; r < 4; ++r) o[r] = gelu_fast(o[r]);
             }
             if (out_f) *(float4*)(out_f + row * out_ld + c) = make_float4(o[0], o[1], o[2], o[3]);
             if (out_h) {
