@@ -58,6 +58,17 @@ class _Profile:
 PROFILE = _Profile()
 
 
+class _Tuner:
+    """Per-plan tile selection by measurement.  While ``active`` every ``GemmPlan.run`` times each candidate
+    tile on its real operands (results of that pass are garbage for in-place plans: use it only on a
+    throw-away warm-up call, e.g. ``ExplainPipeline.tune``) and keeps the fastest."""
+    active = False
+    log = []
+
+
+TUNER = _Tuner()
+
+
 def round_up(x: int, m: int) -> int:
     return (x + m - 1) // m * m
 
@@ -152,7 +163,9 @@ class GemmPlan:
             d.resid, d.resid_f32 = None, 0
         if stream is None:
             stream = torch.cuda.current_stream().cuda_stream
-        prof = PROFILE.enabled and self.tile == TILE_128x128
+        if TUNER.active and not getattr(self, "_tuned", False):
+            self._tune(d, stream)
+        prof = PROFILE.enabled and self.tile in (TILE_128x128, TILE_256x256, TILE_256x128)
         if prof:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -160,6 +173,28 @@ class GemmPlan:
         if prof:
             e1.record()
             PROFILE.events.append((e0, e1, self.flops))
+
+
+def _tune(self, d, stream):
+    cands = [TILE_128x128, TILE_256x256, TILE_256x128] if self.desc.N > 64 else [self.tile]
+    best, best_ms = self.tile, None
+    if len(cands) > 1:
+        for t in cands:
+            _lib.check(_lib.lib().advh_gemm_f16(C.byref(d), t, stream), "advh_gemm_f16")
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                _lib.check(_lib.lib().advh_gemm_f16(C.byref(d), t, stream), "advh_gemm_f16")
+            e1.record()
+            e1.synchronize()
+            ms = e0.elapsed_time(e1) / 3
+            if best_ms is None or ms < best_ms:
+                best, best_ms = t, ms
+        TUNER.log.append((self.desc.M, self.desc.N, self.K, self.desc.nz, TILE_NAMES[best], best_ms))
+    self.tile, self._tuned = best, True
+
+
+GemmPlan._tune = _tune
 
 
 # ------------------------------------------------------------------------------------------ layouts
