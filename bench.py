@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--verbose", action="store_true")
     ap.add_argument("--no-tune", action="store_true", help="keep the default 128x128 GEMM tile everywhere")
     ap.add_argument("--cpu-clips", type=int, default=4)
     ap.add_argument("--cpu-threads", type=int, default=16, help="host threads for the CPU baseline (a 1-GPU box owns 16)")
@@ -81,6 +82,9 @@ def main():
 
     if not args.no_tune:
         pipe.tune(B)                                   # per-launch GEMM tile selection, outside the timed region
+        if args.verbose and rank == 0:
+            for rec in G.TUNER.log:
+                print("tuned", rec, file=sys.stderr)
     for i in range(args.warmup):
         pipe.explain(batches[i % n_batches])
     barrier()

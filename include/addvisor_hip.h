@@ -113,6 +113,7 @@ typedef struct advh_gemm_desc {
     int32_t act;          /* ADVH_ACT_*                                      */
     float slope;          /* LeakyReLU slope                                 */
     int32_t resid_f32;    /* 1: resid is fp32, 0: fp16                       */
+    int32_t ktab_identity;/* 1: ktab[c] == c for all c (plain GEMM rows): kernels may skip the lookup */
 } advh_gemm_desc;
 
 int advh_gemm_f16(const advh_gemm_desc* desc, int tile, advh_stream_t stream);

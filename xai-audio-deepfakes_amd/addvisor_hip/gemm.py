@@ -36,7 +36,7 @@ class GemmDesc(C.Structure):
         ("o_sB", C.c_int64), ("o_sH", C.c_int64), ("o_sW", C.c_int64), ("o_c0", C.c_int64),
         ("o_sNhi", C.c_int64), ("o_sZ", C.c_int64),
         ("n_div", C.c_int32), ("nz", C.c_int32), ("act", C.c_int32), ("slope", C.c_float),
-        ("resid_f32", C.c_int32),
+        ("resid_f32", C.c_int32), ("ktab_identity", C.c_int32),
     ]
 
 
@@ -137,6 +137,7 @@ class GemmPlan:
         d.n_div = n_div if n_div is not None else round_up(N, 4)
         d.nz = nz
         d.act, d.slope = ACT[act], slope
+        d.ktab_identity = int(bool((kt == np.arange(len(kt))).all()))
         self.desc = d
         self.nsrc = len(sources)
         self.flops = 2.0 * M * N * K * nz          # algorithmic (unpadded) FLOPs of this launch

@@ -229,7 +229,7 @@ static int launch(const advh_gemm_desc& d, hipStream_t s) {
 // right after the barrier that publishes K-tile t and stays in flight under the 64 MFMAs per wavefront of
 // tile t; one barrier per K-step.  Wave tile (BM/WM) x (BN/WN) = 128 x 64 for 256 x 256: 24 ds_read_b128
 // feed 64 MFMAs (the 128 x 128 kernel needs 16 per 32), which is what lifts the LDS-read bound.
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int STAGES>
 __global__ __launch_bounds__(512) void gemm_f16_pipe_kernel(const advh_gemm_desc p) {
     constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 16, NI = TN / 16;
     constexpr int NA = BM / 64, NB = BN / 64;      // 16-byte chunks per thread per K-step (512 threads)
@@ -290,8 +290,11 @@ __global__ __launch_bounds__(512) void gemm_f16_pipe_kernel(const advh_gemm_desc
         for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nk = p.Ktot / BK;
-    auto issue = [&](int kt, int kq) {
-        char* st = dsmem + (kt & 1) * STAGE;
+    const int* ktab = p.ktab;
+    auto issue = [&](int kt) {
+        // identity tables (plain GEMM / conv1d rows) need no lookup; otherwise a cached 4-byte load
+        const int kq = p.ktab_identity ? kt * 8 + q : ktab[kt * 8 + q];
+        char* st = dsmem + (kt % STAGES) * STAGE;
         const bool s1 = kq < 0;
         const unsigned ko = (unsigned)kq & 0x7fffffffu;
         const _Float16* base = s1 ? A1 : A0;
@@ -305,17 +308,18 @@ __global__ __launch_bounds__(512) void gemm_f16_pipe_kernel(const advh_gemm_desc
             __builtin_amdgcn_global_load_lds(GLOBAL_PTR(wrow[i] + kt * BK),
                                              LDS_PTR(st + BM * BK * 2 + (wv * 64 + 512 * i) * 16), 16, 0, 0);
     };
-    int kq = p.ktab[q];
-    issue(0, kq);
-    if (nk > 1) kq = p.ktab[8 + q];
+    // prologue: STAGES-1 tiles in flight
+#pragma unroll
+    for (int t = 0; t < STAGES - 1; ++t)
+        if (t < nk) issue(t);
     for (int kt = 0; kt < nk; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // tile kt (and the ktab prefetch) landed
-        __builtin_amdgcn_s_barrier();                          // ... for every wavefront; stage (kt+1)&1 is free
-        if (kt + 1 < nk) {
-            issue(kt + 1, kq);                                 // in flight under the MFMAs below
-            if (kt + 2 < nk) kq = p.ktab[(kt + 2) * 8 + q];
-        }
-        const char* st = dsmem + (kt & 1) * STAGE;
+        // tile kt landed for this wavefront: at most the STAGES-2 younger tiles may stay in flight
+        if (STAGES == 2 || kt + 1 >= nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (STAGES == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + NB) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (NA + NB)) : "memory");
+        __builtin_amdgcn_s_barrier();                          // ... for every wavefront; stage (kt-1)%STAGES is free
+        if (kt + STAGES - 1 < nk) issue(kt + STAGES - 1);      // in flight under the next STAGES-1 compute phases
+        const char* st = dsmem + (kt % STAGES) * STAGE;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             f16x8 a[MI], b[NI];
@@ -333,12 +337,12 @@ __global__ __launch_bounds__(512) void gemm_f16_pipe_kernel(const advh_gemm_desc
     gemm_epilogue<MI, NI>(p, acc, m0 + wm * TM, n0 + wn * TN, fr, fq, z);
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int STAGES>
 static int launch_pipe(const advh_gemm_desc& d, hipStream_t s) {
     const int tilesM = (d.M + BM - 1) / BM, tilesN = (d.N + BN - 1) / BN;
     if (tilesN * BN > d.w_rows) return ADVH_EINVAL;
     dim3 grid(tilesM * tilesN, 1, d.nz > 0 ? d.nz : 1);
-    hipLaunchKernelGGL((gemm_f16_pipe_kernel<BM, BN, WM, WN>), grid, dim3(512), 2 * (BM + BN) * BK * 2, s, d);
+    hipLaunchKernelGGL((gemm_f16_pipe_kernel<BM, BN, WM, WN, STAGES>), grid, dim3(512), STAGES * (BM + BN) * BK * 2, s, d);
     return ADVH_LAUNCH_CHECK();
 }
 
@@ -348,8 +352,8 @@ using namespace advh;
 
 int advh_init_rest() {
     const int maxlds = 160 * 1024;
-    if (hipFuncSetAttribute((const void*)gemm_f16_pipe_kernel<256, 256, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, maxlds) != hipSuccess) return ADVH_ELAUNCH;
-    if (hipFuncSetAttribute((const void*)gemm_f16_pipe_kernel<256, 128, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, maxlds) != hipSuccess) return ADVH_ELAUNCH;
+    if (hipFuncSetAttribute((const void*)gemm_f16_pipe_kernel<256, 256, 2, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, maxlds) != hipSuccess) return ADVH_ELAUNCH;
+    if (hipFuncSetAttribute((const void*)gemm_f16_pipe_kernel<256, 128, 4, 2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, maxlds) != hipSuccess) return ADVH_ELAUNCH;
     return ADVH_OK;
 }
 
@@ -365,8 +369,8 @@ extern "C" int advh_gemm_f16(const advh_gemm_desc* d, int tile, advh_stream_t st
         case ADVH_TILE_128x128: return launch<128, 128, 2, 2>(*d, s);
         case ADVH_TILE_256x64: return launch<256, 64, 4, 1>(*d, s);
         case ADVH_TILE_256x32: return launch<256, 32, 4, 1>(*d, s);
-        case ADVH_TILE_256x256: return launch_pipe<256, 256, 2, 4>(*d, s);
-        case ADVH_TILE_256x128: return launch_pipe<256, 128, 4, 2>(*d, s);
+        case ADVH_TILE_256x256: return launch_pipe<256, 256, 2, 4, 2>(*d, s);
+        case ADVH_TILE_256x128: return launch_pipe<256, 128, 4, 2, 3>(*d, s);
         default: return ADVH_EINVAL;
     }
 }
