@@ -114,6 +114,12 @@ typedef struct advh_gemm_desc {
     float slope;          /* LeakyReLU slope                                 */
     int32_t resid_f32;    /* 1: resid is fp32, 0: fp16                       */
     int32_t ktab_identity;/* 1: ktab[c] == c for all c (plain GEMM rows): kernels may skip the lookup */
+    void* out_h2;         /* optional second fp16 output = LeakyReLU_{slope2}(value written to out_h):
+                             the pre-activated copy the next HiFi-GAN conv consumes (ResBlock1)          */
+    float slope2;
+    /* ConvTranspose1d by phase decomposition (stride r = ph_r > 0): column block n / n_div is the output phase,
+       row w the input position; the element is written only if 0 <= w*ph_r + n/n_div - ph_pad < ph_T.   */
+    int32_t ph_r, ph_pad, ph_T;
 } advh_gemm_desc;
 
 int advh_gemm_f16(const advh_gemm_desc* desc, int tile, advh_stream_t stream);
@@ -175,6 +181,22 @@ int advh_unet_head(const void* y, int B, int H, int W, int PH, int PW, const flo
  * order; per_clip (or NULL) <- [5][n] fp32 per-clip values. */
 int advh_lmac_metrics_accumulate(const float* predictions, const float* theta_out, const float* masked_predictions,
                                  int n, double* sums6, float* per_clip, advh_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * HiFi-GAN V1 generator -- replaces hifi_gan.decode_batch (hifigan.py:106-110, 180; SpeechBrain HIFIGAN,
+ * architecture of Kong et al. 2020 config V1) and the mel front end (hifigan.py:163-178).
+ * The Conv1d / ConvTranspose1d layers are advh_gemm_f16 launches (plans in addvisor_hip/gemm.py); these are
+ * the remaining pieces.  Maps are zero-haloed channels-last fp16 [B][T+2*halo][C].
+ * advh_hifigan_pack_mel : mel [B][C][T] fp32 -> map interior.
+ * advh_hifigan_mrf_mix  : y = LeakyReLU_slope((a+b+c)/3) over `numel` fp16 elements (the MRF average + the
+ *                         activation in front of the next upsampler / conv_post).
+ * advh_hifigan_conv_post: Conv1d(C,1,k,"same") + tanh -> wav [B][1][T] fp32; w is [k][C] fp32.
+ * advh_mel_log          : out [B][n_mels][T] = log(clamp(fb^T |X|, 1e-5)), fb [F][n_mels], mag [B][F][T].     */
+int advh_hifigan_pack_mel(const float* mel, void* out, int B, int C, int T, int halo, advh_stream_t stream);
+int advh_hifigan_mrf_mix(const void* a, const void* b, const void* c, void* y, float slope, int64_t numel, advh_stream_t stream);
+int advh_hifigan_conv_post(const void* x, const float* w, float bias, float* wav, int B, int C, int T, int halo, int k,
+                           advh_stream_t stream);
+int advh_mel_log(const float* mag, const float* fb, float* out, int B, int F, int T, int n_mels, advh_stream_t stream);
 
 #ifdef __cplusplus
 }

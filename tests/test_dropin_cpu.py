@@ -105,3 +105,16 @@ def test_gather_probabilities_gloo_world2(n_total):
     res = [q.get(timeout=120) for _ in procs]
     [p.join(60) for p in procs]
     assert all(ok for _, ok in res) and all(p.exitcode == 0 for p in procs)
+
+
+def test_hifigan_module_and_align():
+    import hifigan
+    from oracle import hifigan_ref
+    assert hasattr(hifigan.hifi_gan, "decode_batch")
+    r = np.random.Generator(np.random.PCG64(9))
+    ref = torch.from_numpy(r.standard_normal(3000).astype(np.float32))
+    for shift in (37, -52, 0):
+        deg = torch.roll(ref, -shift)[:2800] + 0.01 * torch.from_numpy(r.standard_normal(2800).astype(np.float32))
+        a1, b1 = hifigan.align_waveforms(ref, deg)
+        a2, b2 = hifigan_ref.align_waveforms(ref, deg)
+        assert a1.shape == a2.shape == (1, 1, a2.shape[-1]) and torch.equal(a1, a2) and torch.equal(b1, b2)

@@ -87,3 +87,29 @@ def test_convT2d_plan():
         assert torch.allclose(inner, ref, atol=2e-3)
         out[:, 1:1 + dst.H, 1:1 + dst.W, 4:4 + Cout] = float("nan")
         assert torch.isnan(out).all()                          # nothing else is touched
+
+
+def test_conv1d_same_and_convT1d_plans():
+    """HiFi-GAN layers: dilated "same" Conv1d and phase-decomposed ConvTranspose1d (k = 2*stride)."""
+    B, T, C = 2, 13, 16
+    x = rnd(B, C, T)
+    src = G.Map1D(B, T, C, 6)
+    src.t = torch.zeros(B, src.P, C, dtype=torch.float16)
+    src.interior()[:] = x.transpose(1, 2).half()
+    for k, d in ((3, 1), (7, 1), (3, 5), (5, 3)):
+        w, b = rnd(8, C, k) * 0.2, rnd(8)
+        dst = G.Map1D(B, T, 8, 2)
+        p = G.plan_conv1d_same(src, dst, w, b, dilation=d, act="leaky", slope=0.1)
+        out = G.replay_on_cpu(p, src.t, None, B * dst.P * 8).view(B, dst.P, 8)
+        ref = F.leaky_relu(F.conv1d(x.half().float(), w.half().float(), b, padding=(k - 1) * d // 2, dilation=d), 0.1)
+        assert torch.allclose(out[:, 2:2 + T].transpose(1, 2), ref, atol=2e-3)
+        assert (out[:, :2] == 0).all() and (out[:, 2 + T:] == 0).all()
+    for r in (2, 8):
+        w, b = rnd(C, 8, 2 * r) * 0.2, rnd(8)
+        dst = G.Map1D(B, T * r, 8, 5)
+        init = torch.zeros(B * dst.P * 8)
+        p = G.plan_convT1d(src, dst, w, b, stride=r)
+        out = G.replay_on_cpu(p, src.t, None, B * dst.P * 8, out_init=init).view(B, dst.P, 8)
+        ref = F.conv_transpose1d(x.half().float(), w.half().float(), b, stride=r, padding=r // 2)
+        assert torch.allclose(out[:, 5:5 + T * r].transpose(1, 2), ref, atol=2e-3), (out[:, 5:5 + T * r].transpose(1, 2) - ref).abs().max()
+        assert (out[:, :5] == 0).all() and (out[:, 5 + T * r:] == 0).all()       # the halo stays untouched

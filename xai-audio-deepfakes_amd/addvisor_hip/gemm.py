@@ -37,6 +37,7 @@ class GemmDesc(C.Structure):
         ("o_sNhi", C.c_int64), ("o_sZ", C.c_int64),
         ("n_div", C.c_int32), ("nz", C.c_int32), ("act", C.c_int32), ("slope", C.c_float),
         ("resid_f32", C.c_int32), ("ktab_identity", C.c_int32),
+        ("out_h2", C.c_void_p), ("slope2", C.c_float), ("ph_r", C.c_int32), ("ph_pad", C.c_int32), ("ph_T", C.c_int32),
     ]
 
 
@@ -99,7 +100,8 @@ class GemmPlan:
                  Hg: int, Wg: int, window: Tuple[int, int, int, int], halo_zero: bool,
                  out: Tuple[int, int, int, int], n_div: Optional[int] = None, o_sNhi: int = 0,
                  o_sZ: int = 0, nz: int = 1, bias: Optional[torch.Tensor] = None, act: str = "none",
-                 slope: float = 0.0, device=None, w_sZ: Optional[int] = None, bias_sZ: int = 0):
+                 slope: float = 0.0, device=None, w_sZ: Optional[int] = None, bias_sZ: int = 0,
+                 slope2: float = 0.0, phase: Tuple[int, int, int] = (0, 0, 0)):
         """``w2``: fp32 ``[nz, N, K]`` (K = 8 * len(ktab) before padding); ``ktab``: int64 chunk offsets with
         bit 31 as source selector; ``out`` = (o_sB, o_sH, o_sW, o_c0) in elements."""
         assert w2.dim() == 3 and w2.shape[0] == nz and w2.shape[1] == N
@@ -137,14 +139,18 @@ class GemmPlan:
         d.n_div = n_div if n_div is not None else round_up(N, 4)
         d.nz = nz
         d.act, d.slope = ACT[act], slope
+        d.slope2 = slope2
+        d.ph_r, d.ph_pad, d.ph_T = phase
         d.ktab_identity = int(bool((kt == np.arange(len(kt))).all()))
         self.desc = d
         self.nsrc = len(sources)
         self.flops = 2.0 * M * N * K * nz          # algorithmic (unpadded) FLOPs of this launch
 
     def run(self, A0: torch.Tensor, A1: Optional[torch.Tensor] = None, *, out_h: Optional[torch.Tensor] = None,
-            out_f: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None, stream: Optional[int] = None):
+            out_f: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None, stream: Optional[int] = None,
+            out_h2: Optional[torch.Tensor] = None):
         d = self.desc
+        d.out_h2 = out_h2.data_ptr() if out_h2 is not None else None
         assert A0.dtype == torch.float16 and A0.is_cuda
         d.A0 = A0.data_ptr()
         d.A1 = A1.data_ptr() if A1 is not None else None
@@ -312,14 +318,14 @@ def plan_convT2d(src: FMap, dst: FMap, weight: torch.Tensor, bias: torch.Tensor,
 
 # ------------------------------------------------------------------------------------------ CPU replay
 def replay_on_cpu(plan: GemmPlan, A0: torch.Tensor, A1: Optional[torch.Tensor], out_numel: int,
-                  resid: Optional[torch.Tensor] = None) -> torch.Tensor:
+                  resid: Optional[torch.Tensor] = None, out_init: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Execute a plan's descriptor in numpy exactly as the kernel addresses memory (fp32 math).
     Host-logic test aid: checks ktab / strides / windows without a GPU.  Small shapes only."""
     d = plan.desc
     srcs = [A0.reshape(-1).float().numpy(), None if A1 is None else A1.reshape(-1).float().numpy()]
     W = plan.w.float().numpy()
     bias = None if plan.bias is None else plan.bias.numpy().reshape(-1)
-    out = np.full(out_numel, np.nan, dtype=np.float32)
+    out = np.full(out_numel, np.nan, dtype=np.float32) if out_init is None else out_init.reshape(-1).float().numpy().copy()
     kt = plan.ktab_host
     sel, off = (kt >> 31).astype(np.int64), (kt & 0x7FFFFFFF).astype(np.int64)
     for z in range(d.nz):
@@ -350,5 +356,69 @@ def replay_on_cpu(plan: GemmPlan, A0: torch.Tensor, A1: Optional[torch.Tensor], 
                 v = np.where(v > 0, v, d.slope * v)
             if resid is not None:
                 v = v + resid.reshape(-1).float().numpy()[o]
+            if d.ph_r > 0:
+                to = w_ * d.ph_r + cols // d.n_div - d.ph_pad
+                keep = (to >= 0) & (to < d.ph_T)
+                o, v = o[keep], v[keep]
             out[o] = v
     return torch.from_numpy(out)
+
+
+# ------------------------------------------------------------------------------------------ 1-D maps (HiFi-GAN)
+@dataclass
+class Map1D:
+    """Zero-haloed channels-last fp16 sequence ``[B, T + 2*halo, C]`` (C % 8 == 0)."""
+    B: int
+    T: int
+    C: int
+    halo: int
+    t: Optional[torch.Tensor] = None
+
+    @property
+    def P(self):
+        return self.T + 2 * self.halo
+
+    def alloc(self, device):
+        self.t = torch.zeros((self.B, self.P, self.C), dtype=torch.float16, device=device)
+        return self
+
+    def interior(self) -> torch.Tensor:
+        return self.t[:, self.halo:self.halo + self.T]
+
+
+def plan_conv1d_same(src: Map1D, dst: Map1D, weight: torch.Tensor, bias: Optional[torch.Tensor], *, dilation: int = 1,
+                     act: str = "none", slope: float = 0.0, slope2: float = 0.0, device=None) -> GemmPlan:
+    """nn.Conv1d with "same" zero padding ((k-1)*d/2 each side) on zero-haloed channels-last maps: the HiFi-GAN
+    conv_pre and ResBlock1 convolutions.  Enumerates ``dst``'s padded rows and writes its halo as zeros."""
+    Cout, Cin, k = weight.shape
+    pad = (k - 1) * dilation // 2
+    assert src.C == Cin and Cin % 8 == 0 and src.halo >= pad and (src.B, src.T) == (dst.B, dst.T) and Cout <= dst.C
+    cc = Cin // 8
+    kt = (np.arange(k)[:, None] * dilation * cc + np.arange(cc)[None, :]).reshape(-1).astype(np.int64)
+    w2 = weight.permute(0, 2, 1).reshape(1, Cout, k * Cin).float()
+    return GemmPlan(M=dst.B * dst.P, N=Cout, w2=w2, ktab=kt,
+                    sources=[Source(src.P * cc, 0, cc, (src.halo - dst.halo - pad) * cc)], Hg=1, Wg=dst.P,
+                    window=(0, 1, dst.halo, dst.halo + dst.T), halo_zero=True, out=(dst.P * dst.C, 0, dst.C, 0),
+                    bias=bias, act=act, slope=slope, slope2=slope2, device=device)
+
+
+def plan_convT1d(src: Map1D, dst: Map1D, weight: torch.Tensor, bias: torch.Tensor, *, stride: int,
+                 slope2: float = 0.0, device=None) -> GemmPlan:
+    """nn.ConvTranspose1d(k = 2*stride, stride, padding = stride/2) -- the HiFi-GAN upsamplers -- by phase
+    decomposition: output ``t = q*r + phase - pad`` sees exactly the two inputs ``x[q-1], x[q]``, so the layer is
+    a GEMM over input positions q in [0, T_in] with K = 2*Cin (two adjacent channels-last rows = one contiguous
+    slab) and N = r*Cout (phase-major).  Only valid outputs are written; ``dst``'s halo must already be zero."""
+    Cin, Cout, k = weight.shape
+    r = stride
+    pad = (k - r) // 2
+    assert k == 2 * r and src.C == Cin and Cin % 8 == 0 and Cout % 4 == 0 and src.halo >= 1
+    assert dst.T == src.T * r and dst.C == Cout and dst.halo >= pad and dst.B == src.B
+    cc = Cin // 8
+    # w2[n = phase*Cout + co][(tap, ci)]: tap 0 = x[q-1] pairs with W[.., phase + r], tap 1 = x[q] with W[.., phase]
+    wk = weight.permute(2, 1, 0)                                   # [k, Cout, Cin]
+    w2 = torch.cat([wk[r:2 * r], wk[0:r]], dim=2).reshape(1, r * Cout, 2 * Cin).float()
+    return GemmPlan(M=src.B * (src.T + 1), N=r * Cout, w2=w2, ktab=np.arange(2 * cc, dtype=np.int64),
+                    sources=[Source(src.P * cc, 0, cc, (src.halo - 1) * cc)], Hg=1, Wg=src.T + 1,
+                    window=(0, 1, 0, src.T + 1), halo_zero=False,
+                    out=(dst.P * dst.C, 0, r * dst.C, (dst.halo - pad) * dst.C), n_div=Cout, o_sNhi=dst.C,
+                    bias=bias.float().repeat(r), slope2=slope2, phase=(r, pad, dst.T), device=device)

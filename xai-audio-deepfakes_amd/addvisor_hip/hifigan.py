@@ -1,0 +1,104 @@
+"""HiFi-GAN V1 generator on the HIP kernels (reference handle: hifigan.py:106-110, 180).
+
+``decode_batch(mel [B, 80, T]) -> wav [B, 1, T*256]``.  Every Conv1d / ConvTranspose1d is an
+implicit-GEMM launch on zero-haloed channels-last fp16 maps (``gemm.plan_conv1d_same`` /
+``plan_convT1d``); LeakyReLU is applied by the producer (each GEMM writes the raw map for the residual
+path and, through ``out_h2``, the pre-activated copy the next conv reads), the MRF average and the
+1-channel conv_post + tanh are small direct kernels.  Weight-norm is assumed folded (inference form).
+"""
+from __future__ import annotations
+
+from typing import Dict, Tuple
+
+import torch
+
+from . import _lib, gemm as G
+from .synthetic import HifiganConfig
+
+HALO = 32          # >= the largest "same" padding: (11 - 1) * 5 / 2 = 25
+
+
+class HipHifigan:
+    def __init__(self, cfg: HifiganConfig, sd: Dict[str, torch.Tensor], device):
+        _lib.init()
+        self.cfg, self.dev = cfg, device
+        self.sd = {k: v.detach().float() for k, v in sd.items()}
+        ch = cfg.upsample_initial_channel
+        for _ in cfg.upsample_rates:
+            ch //= 2
+        if ch % 8:
+            raise ValueError("every HiFi-GAN stage needs a channel count that is a multiple of 8")
+        if cfg.in_channels % 8:
+            raise ValueError("mel channels must be a multiple of 8")
+        self.post_w = self.sd["conv_post.weight"][0].t().contiguous().to(device)       # [k][C]
+        self.post_b = float(self.sd["conv_post.bias"][0])
+        self._ws: Dict[Tuple[int, int], dict] = {}
+
+    def _workspace(self, B: int, T: int) -> dict:
+        key = (B, T)
+        if key in self._ws:
+            return self._ws[key]
+        cfg, sd, dev = self.cfg, self.sd, self.dev
+        M = lambda t, c: G.Map1D(B, t, c, HALO).alloc(dev)
+        ch = cfg.upsample_initial_channel
+        mel = M(T, cfg.in_channels)
+        cur = M(T, ch)                       # lrelu(conv_pre(mel))
+        steps = [("gemm", G.plan_conv1d_same(mel, cur, sd["conv_pre.weight"], sd["conv_pre.bias"], act="leaky",
+                                             slope=cfg.leaky_slope, device=dev), mel, None, cur, None)]
+        t = T
+        nk, nd = len(cfg.resblock_kernel_sizes), len(cfg.resblock_dilations)
+        nstage = len(cfg.upsample_rates)
+        for i, r in enumerate(cfg.upsample_rates):
+            co, t2 = ch // 2, t * r
+            x, lx = M(t2, co), M(t2, co)
+            steps.append(("gemm", G.plan_convT1d(cur, x, sd[f"ups.{i}.weight"], sd[f"ups.{i}.bias"], stride=r,
+                                                 slope2=cfg.leaky_slope, device=dev), cur, None, x, lx))
+            tmp, pa, la, pb, lb = M(t2, co), M(t2, co), M(t2, co), M(t2, co), M(t2, co)
+            outs = [M(t2, co) for _ in range(nk)]
+            for j in range(nk):
+                p = f"resblocks.{i * nk + j}."
+                cx, clx = x, lx
+                for d in range(nd):
+                    last = d == nd - 1
+                    steps.append(("gemm", G.plan_conv1d_same(clx, tmp, sd[p + f"convs1.{d}.weight"], sd[p + f"convs1.{d}.bias"],
+                                                             dilation=cfg.resblock_dilations[d], act="leaky",
+                                                             slope=cfg.leaky_slope, device=dev), clx, None, tmp, None))
+                    ox = outs[j] if last else (pa if d % 2 == 0 else pb)
+                    ol = None if last else (la if d % 2 == 0 else lb)
+                    steps.append(("gemm", G.plan_conv1d_same(tmp, ox, sd[p + f"convs2.{d}.weight"], sd[p + f"convs2.{d}.bias"],
+                                                             slope2=cfg.leaky_slope, device=dev), tmp, cx, ox, ol))
+                    cx, clx = ox, ol
+            nxt = M(t2, co)
+            slope = cfg.leaky_slope if i < nstage - 1 else 0.01            # F.leaky_relu default before conv_post
+            steps.append(("mix", slope, outs, None, nxt, None))
+            cur, ch, t = nxt, co, t2
+        ws = dict(mel=mel, steps=steps, last=cur, T_out=t, wav=torch.empty(B, 1, t, dtype=torch.float32, device=dev))
+        ws["flops"] = sum(s[1].flops for s in steps if s[0] == "gemm") + 2.0 * B * t * ch * cfg.post_kernel
+        self._ws[key] = ws
+        return ws
+
+    def flops(self, B: int, T: int) -> float:
+        return self._workspace(B, T)["flops"]
+
+    def decode_batch(self, mel: torch.Tensor) -> torch.Tensor:
+        """``mel [B, n_mels, T]`` (fp32, on the GPU) -> ``wav [B, 1, T * hop]`` fp32."""
+        if mel.dim() == 2:
+            mel = mel[None]
+        if mel.dim() != 3 or mel.shape[1] != self.cfg.in_channels:
+            raise ValueError(f"mel must be [B, {self.cfg.in_channels}, T]")
+        mel = mel.to(self.dev, torch.float32).contiguous()
+        B, C, T = mel.shape
+        ws = self._workspace(B, T)
+        lib, st = _lib.lib(), torch.cuda.current_stream().cuda_stream
+        _lib.check(lib.advh_hifigan_pack_mel(mel.data_ptr(), ws["mel"].t.data_ptr(), B, C, T, HALO, st), "advh_hifigan_pack_mel")
+        for kind, plan, src, resid, dst, dst2 in ws["steps"]:
+            if kind == "gemm":
+                plan.run(src.t, out_h=dst.t, resid=None if resid is None else resid.t, out_h2=None if dst2 is None else dst2.t)
+            else:
+                a, b, c = src
+                _lib.check(lib.advh_hifigan_mrf_mix(a.t.data_ptr(), b.t.data_ptr(), c.t.data_ptr(), dst.t.data_ptr(), plan,
+                                                    dst.t.numel(), st), "advh_hifigan_mrf_mix")
+        last = ws["last"]
+        _lib.check(lib.advh_hifigan_conv_post(last.t.data_ptr(), self.post_w.data_ptr(), self.post_b, ws["wav"].data_ptr(), B,
+                                              last.C, last.T, HALO, self.cfg.post_kernel, st), "advh_hifigan_conv_post")
+        return ws["wav"].clone()

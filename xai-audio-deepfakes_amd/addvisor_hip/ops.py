@@ -108,3 +108,48 @@ def istft_complex(spec: torch.Tensor, length: int, hop: int = 322, win: int = 64
     rc = _lib.lib().advh_istft_c64(sr.data_ptr(), out.data_ptr(), length, B, T, length, hop, win, _ptr(window), _stream())
     _lib.check(rc, "advh_istft_c64")
     return out
+
+
+_MEL_FB = {}
+
+
+def mel_filterbank(n_mels=80, n_fft=1024, sr=16000, f_min=0.0, f_max=8000.0) -> torch.Tensor:
+    """Slaney-scale, slaney-normalised triangular filterbank ``[n_fft//2+1, n_mels]`` (the ``norm="slaney",
+    mel_scale="slaney"`` arguments of hifigan.py:171-177), built once on the host in fp64."""
+    import numpy as np
+    key = (n_mels, n_fft, sr, f_min, f_max)
+    if key not in _MEL_FB:
+        f_sp, min_log_hz, logstep = 200.0 / 3, 1000.0, np.log(6.4) / 27.0
+        min_log_mel = min_log_hz / f_sp
+
+        def hz_to_mel(f):
+            f = np.asarray(f, dtype=np.float64)
+            return np.where(f >= min_log_hz, min_log_mel + np.log(np.maximum(f, 1e-10) / min_log_hz) / logstep, f / f_sp)
+
+        def mel_to_hz(m):
+            return np.where(m >= min_log_mel, min_log_hz * np.exp(logstep * (m - min_log_mel)), f_sp * m)
+
+        freqs = np.linspace(0, sr // 2, n_fft // 2 + 1)
+        f_pts = mel_to_hz(np.linspace(hz_to_mel(f_min), hz_to_mel(f_max), n_mels + 2))
+        f_diff = np.diff(f_pts)
+        slopes = f_pts[None, :] - freqs[:, None]
+        fb = np.maximum(0.0, np.minimum(-slopes[:, :-2] / f_diff[:-1], slopes[:, 2:] / f_diff[1:]))
+        fb = fb * (2.0 / (f_pts[2:] - f_pts[:-2]))[None, :]
+        _MEL_FB[key] = torch.from_numpy(fb.astype(np.float32))
+    return _MEL_FB[key]
+
+
+def mel_spectrogram(audio: torch.Tensor, sr=16000, hop=256, win=1024, n_mels=80, f_min=0.0, f_max=8000.0) -> torch.Tensor:
+    """``audio [B, L]`` (or ``[L]``) -> log-mel ``[B, n_mels, 1 + L // hop]``: the SpeechBrain ``mel_spectogram``
+    call of hifigan.py:163-178 (Hann window, power 1, slaney mel, ``log(clamp(., 1e-5))``)."""
+    _lib.init()
+    single = audio.dim() == 1
+    a = _req(audio[None] if single else audio, torch.float32, "audio")
+    B, L = a.shape
+    window = torch.hann_window(win, periodic=True, dtype=torch.float32, device=a.device)
+    _, mag, _ = stft_forward(a, L, hop, win, window=window, want_complex=False, want_phase=False)
+    fb = mel_filterbank(n_mels, NFFT, sr, f_min, f_max).to(a.device)
+    T = mag.shape[2]
+    out = torch.empty((B, n_mels, T), dtype=torch.float32, device=a.device)
+    _lib.check(_lib.lib().advh_mel_log(mag.data_ptr(), fb.data_ptr(), out.data_ptr(), B, NBIN, T, n_mels, _stream()), "advh_mel_log")
+    return out[0] if single else out

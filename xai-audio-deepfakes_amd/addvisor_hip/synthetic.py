@@ -275,7 +275,7 @@ class HifiganConfig:
 
 
 def hifigan_tiny_config() -> HifiganConfig:
-    return HifiganConfig(in_channels=8, upsample_initial_channel=32)
+    return HifiganConfig(in_channels=16, upsample_initial_channel=128)      # stages 64 / 32 / 16 / 8 channels
 
 
 def hifigan_weights(cfg: HifiganConfig = HifiganConfig(), seed: int = WEIGHT_SEED) -> Dict[str, torch.Tensor]:
@@ -300,6 +300,6 @@ def hifigan_weights(cfg: HifiganConfig = HifiganConfig(), seed: int = WEIGHT_SEE
                 sd[p + f"convs2.{d}.weight"] = g.uniform((co, co, rk), 0.5 * math.sqrt(3.0 / (co * rk)))
                 sd[p + f"convs2.{d}.bias"] = g.uniform((co,), 0.05)
         ch = co
-    sd["conv_post.weight"] = g.uniform((1, ch, cfg.post_kernel), math.sqrt(3.0 / (ch * cfg.post_kernel)))
+    sd["conv_post.weight"] = g.uniform((1, ch, cfg.post_kernel), 0.1 * math.sqrt(3.0 / (ch * cfg.post_kernel)))   # keeps tanh out of saturation
     sd["conv_post.bias"] = g.uniform((1,), 0.05)
     return sd

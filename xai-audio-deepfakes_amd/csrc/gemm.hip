@@ -80,6 +80,10 @@ __device__ __forceinline__ void gemm_epilogue(const advh_gemm_desc& p, f32x4 (&a
         for (int ni = 0; ni < NI; ++ni) {
             int n = nw0 + ni * 16 + fq * 4;
             if (n >= p.N) continue;
+            if (p.ph_r > 0) {                              // transposed-conv phase window (column-dependent validity)
+                int to = (int)w * p.ph_r + n / p.n_div - p.ph_pad;
+                if (to < 0 || to >= p.ph_T) continue;
+            }
             long o = orow + (long)(n / p.n_div) * p.o_sNhi + (n % p.n_div);
             f32x4 v = acc[ni][mi];
             if (ok) {
@@ -103,6 +107,12 @@ __device__ __forceinline__ void gemm_epilogue(const advh_gemm_desc& p, f32x4 (&a
             if (p.out_h) {
                 f16x4 hv = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
                 *(f16x4*)((_Float16*)p.out_h + o) = hv;
+            }
+            if (p.out_h2) {
+                f16x4 hv;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) hv[r] = (_Float16)(v[r] > 0.f ? v[r] : p.slope2 * v[r]);
+                *(f16x4*)((_Float16*)p.out_h2 + o) = hv;
             }
         }
     }

@@ -1,0 +1,103 @@
+// HiFi-GAN V1 generator: the pieces that are not GEMM-shaped.  (The Conv1d / ConvTranspose1d layers run
+// on the implicit-GEMM kernel: gemm.plan_conv1d_same / plan_convT1d.)  Reference handle: hifigan.py:106-110,
+// 163-180 (SpeechBrain HIFIGAN.decode_batch + mel_spectogram); architecture per Kong et al. 2020, config V1.
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include "addvisor_hip.h"
+#include "common.h"
+
+namespace advh {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+// mel [B][C][T] fp32 (torch layout) -> zero-haloed channels-last fp16 [B][T+2*halo][C]   (interior only)
+__global__ __launch_bounds__(256) void pack_mel_kernel(const float* __restrict__ mel, _Float16* __restrict__ out,
+                                                       int C, int T, int halo, long total) {
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    int c = (int)(i % C);
+    long r = i / C;
+    int t = (int)(r % T), b = (int)(r / T);
+    out[((long)b * (T + 2 * halo) + t + halo) * C + c] = (_Float16)mel[((long)b * C + c) * T + t];
+}
+
+// MRF mix: y = LeakyReLU_slope((a + b + c) / 3), whole padded maps (zero halo stays zero)
+__global__ __launch_bounds__(256) void mrf_mix_kernel(const f16x8* __restrict__ a, const f16x8* __restrict__ b,
+                                                      const f16x8* __restrict__ c, f16x8* __restrict__ y, float slope, long n8) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+        f16x8 va = a[i], vb = b[i], vc = c[i], o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float v = ((float)va[j] + (float)vb[j] + (float)vc[j]) * (1.f / 3.f);
+            o[j] = (_Float16)(v > 0.f ? v : slope * v);
+        }
+        y[i] = o;
+    }
+}
+
+// conv_post: Conv1d(C -> 1, k, "same") + tanh on a pre-activated zero-haloed map; wav [B][1][T] fp32
+__global__ __launch_bounds__(256) void conv_post_kernel(const _Float16* __restrict__ x, const float* __restrict__ w /*[k][C]*/,
+                                                        float bias, float* __restrict__ wav, int C, int T, int halo, int k, long total) {
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    int t = (int)(i % T), b = (int)(i / T);
+    const _Float16* p = x + ((long)b * (T + 2 * halo) + t + halo - (k - 1) / 2) * C;
+    float acc = bias;
+    for (int j = 0; j < k * C; j += 8) {
+        f16x8 v = *(const f16x8*)(p + j);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc = fmaf((float)v[e], w[j + e], acc);
+    }
+    wav[i] = tanhf(acc);
+}
+
+// log-mel: out[b][m][t] = log(max(sum_f fb[f][m] * mag[b][f][t], 1e-5))   (hifigan.py:163-178)
+__global__ __launch_bounds__(256) void mel_log_kernel(const float* __restrict__ mag, const float* __restrict__ fb,
+                                                      float* __restrict__ out, int F, int T, int NM, long total) {
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    int t = (int)(i % T);
+    long r = i / T;
+    int m = (int)(r % NM), b = (int)(r / NM);
+    const float* mg = mag + (long)b * F * T + t;
+    float acc = 0.f;
+    for (int f = 0; f < F; ++f) acc = fmaf(fb[(long)f * NM + m], mg[(long)f * T], acc);
+    out[i] = logf(fmaxf(acc, 1e-5f));
+}
+
+}  // namespace advh
+
+using namespace advh;
+
+extern "C" int advh_hifigan_pack_mel(const float* mel, void* out, int B, int C, int T, int halo, advh_stream_t stream) {
+    if (!mel || !out || B <= 0 || C <= 0 || T <= 0 || halo < 0) return ADVH_EINVAL;
+    long total = (long)B * C * T;
+    hipLaunchKernelGGL(pack_mel_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, mel, (_Float16*)out, C, T, halo, total);
+    return ADVH_LAUNCH_CHECK();
+}
+
+extern "C" int advh_hifigan_mrf_mix(const void* a, const void* b, const void* c, void* y, float slope, int64_t numel, advh_stream_t stream) {
+    if (!a || !b || !c || !y || numel <= 0 || numel % 8) return ADVH_EINVAL;
+    long n8 = numel / 8;
+    long blocks = (n8 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(mrf_mix_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const f16x8*)a, (const f16x8*)b,
+                       (const f16x8*)c, (f16x8*)y, slope, n8);
+    return ADVH_LAUNCH_CHECK();
+}
+
+extern "C" int advh_hifigan_conv_post(const void* x, const float* w, float bias, float* wav, int B, int C, int T, int halo, int k,
+                                      advh_stream_t stream) {
+    if (!x || !w || !wav || B <= 0 || C <= 0 || C % 8 || T <= 0 || k <= 0 || !(k & 1) || halo < (k - 1) / 2) return ADVH_EINVAL;
+    long total = (long)B * T;
+    hipLaunchKernelGGL(conv_post_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const _Float16*)x, w,
+                       bias, wav, C, T, halo, k, total);
+    return ADVH_LAUNCH_CHECK();
+}
+
+extern "C" int advh_mel_log(const float* mag, const float* fb, float* out, int B, int F, int T, int n_mels, advh_stream_t stream) {
+    if (!mag || !fb || !out || B <= 0 || F <= 0 || T <= 0 || n_mels <= 0) return ADVH_EINVAL;
+    long total = (long)B * n_mels * T;
+    hipLaunchKernelGGL(mel_log_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, mag, fb, out, F, T, n_mels, total);
+    return ADVH_LAUNCH_CHECK();
+}
