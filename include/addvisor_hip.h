@@ -120,6 +120,13 @@ typedef struct advh_gemm_desc {
     /* ConvTranspose1d by phase decomposition (stride r = ph_r > 0): column block n / n_div is the output phase,
        row w the input position; the element is written only if 0 <= w*ph_r + n/n_div - ph_pad < ph_T.   */
     int32_t ph_r, ph_pad, ph_T;
+    /* backward support (input-gradient chain of the frozen embedder, captum_saliency.py:131-135):
+       out_pre: fp16 copy of the value BEFORE `act` (saved for the activation derivative), or NULL;
+       dact_src: fp16 tensor addressed like out; if set, the value is multiplied by GELU'(dact_src[o])
+       (after bias, before resid): turns a dgrad GEMM's output into the gradient w.r.t. the previous
+       layer's pre-activation.                                                                          */
+    void* out_pre;
+    const void* dact_src;
 } advh_gemm_desc;
 
 int advh_gemm_f16(const advh_gemm_desc* desc, int tile, advh_stream_t stream);
@@ -134,10 +141,11 @@ int advh_gemm_f16(const advh_gemm_desc* desc, int tile, advh_stream_t stream);
  * out: fp16 channels-last [B][P0][C0], rows t in [T0,P0) written as zeros; T0 = (L-10)/5 + 1.
  * normalize: 1 = apply zero_mean_unit_var_norm first; 0 = wave is already normalised (the raw
  *   `wav2vec2(input_values)` call of audioprocessor.py:76).
- * stats_ws: [B][2] fp32 workspace (clip mean, 1/(std+1e-7));  norm_ws: [B][C0][2] fp32 (mode 0).   */
+ * stats_ws: [B][2] fp32 workspace (clip mean, 1/(std+1e-7));  norm_ws: [B][C0][2] fp32 (mode 0);
+ * mr_ws: NULL, or [B][C0][2] fp32 <- per-channel (mean, rstd) of the GroupNorm, kept for the backward.  */
 int advh_w2v2_frontend(const float* wave, int64_t wave_stride, int n_in, int B, int L, const float* w0,
                        const float* bias0, const float* gamma, const float* beta, int mode, int normalize, float* stats_ws,
-                       float* norm_ws, void* out, int T0, int P0, int C0, advh_stream_t stream);
+                       float* norm_ws, float* mr_ws, void* out, int T0, int P0, int C0, advh_stream_t stream);
 
 /* LayerNorm over the last dimension (+ optional GELU): nn.LayerNorm call sites of
  * modeling_wav2vec2.py:275-299, 422-434, 575-654, 689-802.  in: [M][in_ld] fp32 (in_is_f32) or fp16;
@@ -147,8 +155,10 @@ int advh_layernorm(const void* in, int in_is_f32, int64_t in_ld, const float* ga
                    advh_stream_t stream);
 
 /* Operand gather of the grouped positional Conv1d (modeling_wav2vec2.py:326-379):
- * h [B][T][H] fp32 -> xg [G][B][T+K][H/G] fp16, data in rows [K/2, K/2+T), zero padding elsewhere. */
-int advh_posconv_gather(const float* h, void* xg, int B, int T, int H, int G, int K, advh_stream_t stream);
+ * h [B][T][H] fp32 -> xg [G][B][T+K][H/G] fp16, data in rows [pad_left, pad_left+T), zeros elsewhere
+ * (forward: pad_left = K/2; input-gradient pass: K/2 - 1 and h is multiplied by GELU'(dact_src), fp16 [B][T][H]). */
+int advh_posconv_gather(const float* h, void* xg, int B, int T, int H, int G, int K, int pad_left, const void* dact_src,
+                        advh_stream_t stream);
 
 /* softmax(Q K^T / sqrt(d)) V without mask (modeling_wav2vec2.py:438-548), T <= 256, d in {32, 64}.
  * qkv [B*T][3H] fp16 (q | k | v), ctx [B*T][H] fp16. */
@@ -197,6 +207,36 @@ int advh_hifigan_mrf_mix(const void* a, const void* b, const void* c, void* y, f
 int advh_hifigan_conv_post(const void* x, const float* w, float bias, float* wav, int B, int C, int T, int halo, int k,
                            advh_stream_t stream);
 int advh_mel_log(const float* mag, const float* fb, float* out, int B, int F, int T, int n_mels, advh_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Input-gradient chain of the frozen embedder -- what captum.attr.{Saliency, InputXGradient,
+ * IntegratedGradients}(Wav2vec2LogReg) obtain from autograd (captum_saliency.py:84-100, 116-135).
+ * Dense products are advh_gemm_f16 launches with transposed weights (dact_src / out_pre above); these are
+ * the remaining pieces.  Gradients are fp16 between GEMMs, multiplied by a power-of-two loss scale.
+ *
+ * advh_layernorm_bwd : dx of y = LN(x)*gamma+beta [then GELU if gelu_fwd] given dy; optionally times
+ *                      GELU'(dact_src) and plus `add`; out_f (fp32) and/or out_h (fp16), all [M][C]; with
+ *                      remap_P > 0 output row b*remap_T + t is written at row b*remap_P + t.
+ * advh_attention_bwd_f16 : dqkv [B*T][3H] from qkv and dctx [B*T][H] (fp16), T <= 256, head_dim 32 / 64.
+ * advh_pool_logreg_bwd   : dh[b][t][:] = coef * dlogit[b] / T  (fp32 and/or fp16).
+ * advh_w2v2_frontend_bwd_group : dz0 [B][P0][C0] fp16 from dy0 for the GroupNorm front end (z0 recomputed).
+ * advh_wave_bwd      : g [B][P0][16] fp32 (= dz0 . w0, columns 0..9) -> dx [B][dx_stride] through the
+ *                      stride-5 overlap and the normaliser's Jacobian; multiplied by out_scale (1/loss scale).
+ * advh_scale_rows    : y[r][:] = alpha[r] * x[r % x_rows][:] (+ y): IG path points and step accumulation.   */
+int advh_layernorm_bwd(const void* x, int x_is_f32, const void* dy, int dy_is_f32, const float* gamma, const float* beta,
+                       int gelu_fwd, const float* add, const void* dact_src, float* out_f, void* out_h, int M, int C,
+                       float eps, int remap_T, int remap_P, advh_stream_t stream);
+int advh_attention_bwd_f16(const void* qkv, const void* dctx, void* dqkv, int B, int T, int H, int heads, advh_stream_t stream);
+int advh_pool_logreg_bwd(const float* coef, const float* dlogit, float* dh, void* dh16, int B, int T, int H, advh_stream_t stream);
+int advh_w2v2_frontend_bwd_group(const float* wave, int64_t wave_stride, int n_in, int B, int L, const float* w0,
+                                 const float* gamma, const float* stats_ws, const float* norm_ws, const float* mr_ws,
+                                 const void* dy0, float* part_ws, float* sums_ws, void* dz0, int T0, int P0, int C0,
+                                 advh_stream_t stream);
+int advh_wave_bwd(const float* g, const float* wave, int64_t wave_stride, int n_in, int B, int L, const float* stats_ws,
+                  float* dxhat_ws, float* part_ws, int normalize, float out_scale, float* dx, int64_t dx_stride, int T0, int P0,
+                  advh_stream_t stream);
+int advh_scale_rows(const float* x, int x_rows, const float* alpha, float* y, int rows, int64_t n, int accumulate,
+                    advh_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -41,9 +41,9 @@ SIGNATURES = {
     "advh_istft_masked": (_i, [_p, _p, _p, _i, _i, _i, _p, _p, _i64, _i, _i, _i, _i, _i, _p, _p]),
     "advh_istft_c64": (_i, [_p, _p, _i64, _i, _i, _i, _i, _i, _p, _p]),
     "advh_gemm_f16": (_i, [_p, _i, _p]),
-    "advh_w2v2_frontend": (_i, [_p, _i64, _i, _i, _i, _p, _p, _p, _p, _i, _i, _p, _p, _p, _i, _i, _i, _p]),
+    "advh_w2v2_frontend": (_i, [_p, _i64, _i, _i, _i, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _i, _i, _i, _p]),
     "advh_layernorm": (_i, [_p, _i, _i64, _p, _p, _p, _p, _i64, _i, _i, _f, _i, _p]),
-    "advh_posconv_gather": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
+    "advh_posconv_gather": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p, _p]),
     "advh_attention_f16": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "advh_pool_logreg": (_i, [_p, _p, _f, _p, _p, _p, _i, _i, _i, _p]),
     "advh_unet_stem": (_i, [_p, _i, _i, _i, _i, _i, _p, _p, _p, _i, _i, _f, _p]),
@@ -54,6 +54,12 @@ SIGNATURES = {
     "advh_hifigan_mrf_mix": (_i, [_p, _p, _p, _p, _f, _i64, _p]),
     "advh_hifigan_conv_post": (_i, [_p, _p, _f, _p, _i, _i, _i, _i, _i, _p]),
     "advh_mel_log": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
+    "advh_layernorm_bwd": (_i, [_p, _i, _p, _i, _p, _p, _i, _p, _p, _p, _p, _i, _i, _f, _i, _i, _p]),
+    "advh_attention_bwd_f16": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
+    "advh_pool_logreg_bwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
+    "advh_w2v2_frontend_bwd_group": (_i, [_p, _i64, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    "advh_wave_bwd": (_i, [_p, _p, _i64, _i, _i, _i, _p, _p, _p, _i, _f, _p, _i64, _i, _i, _p]),
+    "advh_scale_rows": (_i, [_p, _i, _p, _p, _i, _i64, _i, _p]),
 }
 
 _lib = None

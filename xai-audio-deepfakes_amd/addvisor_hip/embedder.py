@@ -90,7 +90,7 @@ class HipEmbedder:
             prod = 1
             for j in range(i + 1, nfe):
                 prod *= strides[j]
-            P_last = max(P_last, -(-Ls[i] // prod))
+            P_last = max(P_last, -(-(Ls[i] + 1) // prod))      # >= 1 zero filler row per clip (the backward relies on it)
         P = [0] * nfe
         P[-1] = P_last
         for i in range(nfe - 2, -1, -1):
@@ -102,6 +102,7 @@ class HipEmbedder:
         ws = dict(B=B, L=L, Ls=Ls, P=P, T=T, M=M)
         ws["stats"] = torch.empty(B, 2, dtype=f32, device=dev)
         ws["norm"] = torch.empty(B, C[0], 2, dtype=f32, device=dev)
+        ws["mr"] = torch.empty(B, C[0], 2, dtype=f32, device=dev)
         ws["fe"] = [torch.empty(B * P[0] * C[0], dtype=h16, device=dev),
                     torch.empty(B * P[1] * C[1], dtype=h16, device=dev)]
         ws["feat"] = torch.empty(M, C[-1], dtype=h16, device=dev)
@@ -181,7 +182,8 @@ class HipEmbedder:
         _lib.check(lib.advh_w2v2_frontend(
             wave.data_ptr(), wave.stride(0), n_in, B, L, self.w0.data_ptr(),
             None if self.b0 is None else self.b0.data_ptr(), ln0.g.data_ptr(), ln0.b.data_ptr(), mode, int(normalize),
-            ws["stats"].data_ptr(), ws["norm"].data_ptr(), a.data_ptr(), Ls[0], P[0], C[0], st), "advh_w2v2_frontend")
+            ws["stats"].data_ptr(), ws["norm"].data_ptr(), ws["mr"].data_ptr(), a.data_ptr(), Ls[0], P[0], C[0], st),
+            "advh_w2v2_frontend")
         if self.layer_mode:
             ln0(a, B * P[0], 1e-5, out_h=a, gelu=True)
         cur, nxt = a, bbuf
@@ -197,7 +199,7 @@ class HipEmbedder:
         self.fp_ln(ws["feat"], M, eps, out_h=ws["featn"])
         ws["proj"].run(ws["featn"], out_f=h)
         K, Gp = cfg.num_conv_pos_embeddings, cfg.num_conv_pos_embedding_groups
-        _lib.check(lib.advh_posconv_gather(h.data_ptr(), ws["xg"].data_ptr(), B, T, H, Gp, K, st), "advh_posconv_gather")
+        _lib.check(lib.advh_posconv_gather(h.data_ptr(), ws["xg"].data_ptr(), B, T, H, Gp, K, K // 2, None, st), "advh_posconv_gather")
         ws["pos"].run(ws["xg"], out_f=h, resid=h)                     # h += gelu(pos_conv(h))
         stable = cfg.do_stable_layer_norm
         if not stable:

@@ -1,0 +1,231 @@
+"""Input gradient of the frozen classifier  F(x) = logreg(mean_t(hidden_states[k](wav2vec2(norm(x)))))
+on the HIP kernels: the quantity Captum's Saliency / InputXGradient / IntegratedGradients differentiate
+(captum_saliency.py:84-100, 116-135).
+
+The weights are frozen, so the backward pass is dgrad-only: every dense product is the forward's implicit GEMM
+with the transposed weight (``gemm.plan_linear(W.T)``, ``plan_conv1d_dgrad``), with the activation derivative
+(``dact_src``) fused in its epilogue; LayerNorm, attention and the waveform front end have dedicated backward
+kernels (csrc/backward.hip, frontend_bwd.hip).  The forward of this class is the same arithmetic as
+``HipEmbedder.forward`` but writes every tensor the backward needs (pre-activations, LayerNorm inputs, QKV)
+to its own buffer instead of updating in place.
+
+Gradients travel as fp16 between GEMMs multiplied by ``loss_scale`` (a power of two: exact), the residual-stream
+gradient is fp32.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib, gemm as G
+from .embedder import HipEmbedder
+
+
+def plan_conv1d_dgrad(B: int, P_out: int, weight: torch.Tensor, stride: int, device=None) -> G.GemmPlan:
+    """Input gradient of the channels-last Conv1d of ``gemm.plan_conv1d_cl`` (no padding): position
+    ``u = s*q + phase`` of the input receives ``sum_{i} dZ[q - (nt-1) + i] . W[:, :, phase + s*(nt-1-i)]``
+    (nt = ceil(k/s) taps), so the layer is a GEMM over rows q with K = nt*Cout (nt adjacent dZ rows = one
+    contiguous slab) and N = s*Cin, whose row q of the output is input rows s*q .. s*q+s-1.
+    ``A0`` must point ``nt-1`` rows BEFORE dZ[0] (a zero guard row), and every clip needs >= 1 zero filler row."""
+    Cout, Cin, k = weight.shape
+    s = stride
+    nt = -(-k // s)
+    assert Cout % 8 == 0 and Cin % 4 == 0
+    w2 = torch.zeros(s * Cin, nt * Cout)
+    for phase in range(s):
+        for i in range(nt):
+            j = phase + s * (nt - 1 - i)
+            if j < k:
+                w2[phase * Cin:(phase + 1) * Cin, i * Cout:(i + 1) * Cout] = weight[:, :, j].t()
+    cc = Cout // 8
+    return G.GemmPlan(M=B * P_out, N=s * Cin, w2=w2[None], ktab=np.arange(nt * cc, dtype=np.int64),
+                      sources=[G.Source(P_out * cc, 0, cc, 0)], Hg=1, Wg=P_out, window=(0, 1, 0, P_out), halo_zero=False,
+                      out=(P_out * s * Cin, 0, s * Cin, 0), device=device), nt
+
+
+class EmbedderGrad:
+    def __init__(self, emb: HipEmbedder):
+        self.emb = emb
+        self.cfg, self.dev, self.sd = emb.cfg, emb.dev, emb.sd
+        if self.cfg.feat_extract_norm != "group" or self.cfg.do_stable_layer_norm:
+            raise NotImplementedError("input-gradient path is built for the group-norm / post-LN embedder (wav2vec2-base)")
+        self._ws: Dict[Tuple[int, int], dict] = {}
+
+    # ------------------------------------------------------------------ buffers and plans
+    def _workspace(self, B: int, L: int) -> dict:
+        key = (B, L)
+        if key in self._ws:
+            return self._ws[key]
+        emb, cfg, dev, sd = self.emb, self.cfg, self.dev, self.sd
+        f = emb._workspace(B, L)                      # forward plans / shapes are shared
+        Ls, P, T, M = f["Ls"], f["P"], f["T"], f["M"]
+        for i in range(len(Ls)):
+            if P[i] <= Ls[i]:
+                raise ValueError("backward needs one zero filler row per clip (P > L)")
+        H, I, C = cfg.hidden_size, cfg.intermediate_size, cfg.conv_dim
+        nfe, nl = len(Ls), emb.nl
+        h16, f32 = torch.float16, torch.float32
+        z = lambda *s, dt=h16: torch.zeros(*s, dtype=dt, device=dev)
+        w = dict(f=f)
+        # forward saves ------------------------------------------------------------------
+        w["y"] = [z(B * P[i] * C[i]) for i in range(nfe - 1)]                    # post-GELU outputs of layers 0..5
+        w["z"] = [None] + [z(B * P[i] * C[i]) for i in range(1, nfe - 1)] + [z(M, C[-1])]   # pre-GELU of layers 1..6
+        w["feat"] = z(M, C[-1])
+        w["pc"] = z(M, H)                                                        # pre-GELU positional conv
+        w["h1"] = z(M, H, dt=f32)                                                # input of encoder.layer_norm
+        w["x"] = [z(M, H, dt=f32) for _ in range(nl + 1)]                        # layer inputs / final output
+        w["qkv"] = [z(M, 3 * H) for _ in range(nl)]
+        w["s1"] = [z(M, H, dt=f32) for _ in range(nl)]
+        w["m"] = [z(M, H, dt=f32) for _ in range(nl)]
+        w["g1"] = [z(M, I) for _ in range(nl)]
+        w["s2"] = [z(M, H, dt=f32) for _ in range(nl)]
+        # backward scratch ---------------------------------------------------------------
+        w["dlogit"] = z(B, dt=f32)
+        w["da"] = z(M, H, dt=f32)
+        w["db"] = z(M, H, dt=f32)
+        w["d16"] = z(M, H)
+        w["dI"] = z(M, I)
+        w["dctx"] = z(M, H)
+        w["dqkv"] = z(M, 3 * H)
+        w["dfeatn"] = z(M, C[-1])
+        # dZ_i: per-clip padded layout [B][P_i][C_i] with one zero guard row in front
+        w["dz"] = [z((B * P[i] + 1) * C[i]) for i in range(nfe)]
+        w["g"] = z(B * P[0], 16, dt=f32)
+        ntile = -(-P[0] // 64)
+        w["part"] = z(B, ntile, C[0], 2, dt=f32)
+        w["sums"] = z(B, C[0], 2, dt=f32)
+        w["dxh"] = z(B, L, dt=f32)
+        w["wpart"] = z(B, -(-L // 2048), 2, dt=f32)
+        # backward plans -----------------------------------------------------------------
+        lin = lambda wt, **kw: G.plan_linear(M, wt, None, device=dev, **kw)
+        layers = []
+        for l in range(nl):
+            p = f"encoder.layers.{l}."
+            wqkv = torch.cat([sd[p + f"attention.{n}_proj.weight"] for n in ("q", "k", "v")], 0)
+            layers.append(dict(ff2=lin(sd[p + "feed_forward.output_dense.weight"].t()),
+                               ff1=lin(sd[p + "feed_forward.intermediate_dense.weight"].t()),
+                               out=lin(sd[p + "attention.out_proj.weight"].t()), qkv=lin(wqkv.t())))
+        w["layers"] = layers
+        w["proj"] = lin(sd["feature_projection.projection.weight"].t())
+        K, Gp = cfg.num_conv_pos_embeddings, cfg.num_conv_pos_embedding_groups
+        Cg, cc = H // Gp, H // Gp // 8
+        g0 = sd["encoder.pos_conv_embed.conv.parametrizations.weight.original0"]
+        v0 = sd["encoder.pos_conv_embed.conv.parametrizations.weight.original1"]
+        wpos = (g0 * v0 / v0.pow(2).sum(dim=(0, 1), keepdim=True).sqrt()).view(Gp, Cg, Cg, K)        # [g][co][ci][k]
+        w2b = wpos.flip(3).permute(0, 2, 3, 1).reshape(Gp, Cg, K * Cg)                                 # [g][ci][(k', co)]
+        w["pos"] = G.GemmPlan(M=M, N=Cg, w2=w2b, ktab=np.arange(K * cc, dtype=np.int64),
+                              sources=[G.Source((T + K) * cc, 0, cc, 0, sZ=B * (T + K) * cc)], Hg=1, Wg=T,
+                              window=(0, 1, 0, T), halo_zero=False, out=(T * H, 0, H, 0), n_div=G.round_up(Cg, 4),
+                              o_sZ=Cg, nz=Gp, device=dev)
+        fe = []
+        for i in range(1, nfe):
+            plan, nt = plan_conv1d_dgrad(B, P[i], sd[f"feature_extractor.conv_layers.{i}.conv.weight"], cfg.conv_stride[i], dev)
+            fe.append((plan, nt))
+        w["fe"] = fe
+        w0t = torch.zeros(16, C[0])
+        w0t[:10] = sd["feature_extractor.conv_layers.0.conv.weight"].reshape(C[0], 10).t()
+        w["g_plan"] = G.plan_linear(B * P[0], w0t, None, device=dev)
+        self._ws[key] = w
+        return w
+
+    # ------------------------------------------------------------------ forward with saves
+    def forward(self, wave: torch.Tensor, length: Optional[int] = None):
+        emb, cfg, lib = self.emb, self.cfg, _lib.lib()
+        wave = wave.contiguous()
+        B, n_in = wave.shape
+        L = n_in if length is None else int(length)
+        w = self._workspace(B, L)
+        f = w["f"]
+        st = torch.cuda.current_stream().cuda_stream
+        Ls, P, T, M, H = f["Ls"], f["P"], f["T"], f["M"], cfg.hidden_size
+        eps, C, nfe = cfg.layer_norm_eps, cfg.conv_dim, len(f["Ls"])
+        ln0 = emb.fe_ln[0]
+        _lib.check(lib.advh_w2v2_frontend(
+            wave.data_ptr(), wave.stride(0), n_in, B, L, emb.w0.data_ptr(), None, ln0.g.data_ptr(), ln0.b.data_ptr(), 0, 1,
+            f["stats"].data_ptr(), f["norm"].data_ptr(), f["mr"].data_ptr(), w["y"][0].data_ptr(), Ls[0], P[0], C[0], st),
+            "advh_w2v2_frontend")
+        for i in range(1, nfe):
+            last = i == nfe - 1
+            f["fe_plans"][i - 1].run(w["y"][i - 1], out_h=w["feat"] if last else w["y"][i], out_pre=w["z"][i])
+        emb.fp_ln(w["feat"], M, eps, out_h=f["featn"])
+        h = f["h"]
+        f["proj"].run(f["featn"], out_f=h)
+        K, Gp = cfg.num_conv_pos_embeddings, cfg.num_conv_pos_embedding_groups
+        _lib.check(lib.advh_posconv_gather(h.data_ptr(), f["xg"].data_ptr(), B, T, H, Gp, K, K // 2, None, st), "advh_posconv_gather")
+        f["pos"].run(f["xg"], out_f=w["h1"], resid=h, out_pre=w["pc"])
+        h16 = f["h16"]
+        emb.enc_ln(w["h1"], M, eps, out_f=w["x"][0], out_h=h16)
+        for l in range(emb.nl):
+            lay = f["layers"][l]
+            lay["qkv"].run(h16, out_h=w["qkv"][l])
+            _lib.check(lib.advh_attention_f16(w["qkv"][l].data_ptr(), f["ctx"].data_ptr(), B, T, H, cfg.num_attention_heads, st),
+                       "advh_attention_f16")
+            lay["out"].run(f["ctx"], out_f=w["s1"][l], resid=w["x"][l])
+            emb.ln1[l](w["s1"][l], M, eps, out_f=w["m"][l], out_h=h16)
+            lay["ff1"].run(h16, out_h=f["ffn"], out_pre=w["g1"][l])
+            lay["ff2"].run(f["ffn"], out_f=w["s2"][l], resid=w["m"][l])
+            emb.ln2[l](w["s2"][l], M, eps, out_f=w["x"][l + 1], out_h=h16)
+        _lib.check(lib.advh_pool_logreg(w["x"][emb.nl].data_ptr(), emb.coef.data_ptr(), emb.intercept, f["logit"].data_ptr(),
+                                        f["prob"].data_ptr(), None, B, T, H, st), "advh_pool_logreg")
+        self._last = (wave, B, n_in, L)
+        return f["logit"].clone().view(B, 1), f["prob"].clone().view(B, 1)
+
+    # ------------------------------------------------------------------ backward
+    def _ln_bwd(self, ln, x, dy, M, out_f=None, out_h=None, add=None, dact=None, remap=(0, 0)):
+        _lib.check(_lib.lib().advh_layernorm_bwd(
+            x.data_ptr(), int(x.dtype == torch.float32), dy.data_ptr(), int(dy.dtype == torch.float32), ln.g.data_ptr(),
+            ln.b.data_ptr(), 0, None if add is None else add.data_ptr(), None if dact is None else dact.data_ptr(),
+            None if out_f is None else out_f.data_ptr(), None if out_h is None else out_h.data_ptr(), M, ln.C,
+            self.cfg.layer_norm_eps, remap[0], remap[1], torch.cuda.current_stream().cuda_stream), "advh_layernorm_bwd")
+
+    def backward(self, loss_scale: float = 4096.0) -> torch.Tensor:
+        """d logit / d wave for the clips of the last ``forward`` call: ``[B, n_in]`` fp32."""
+        emb, cfg, lib = self.emb, self.cfg, _lib.lib()
+        wave, B, n_in, L = self._last
+        w = self._workspace(B, L)
+        f = w["f"]
+        st = torch.cuda.current_stream().cuda_stream
+        Ls, P, T, M, H = f["Ls"], f["P"], f["T"], f["M"], cfg.hidden_size
+        C, nfe, nl = cfg.conv_dim, len(f["Ls"]), emb.nl
+        da, db, d16 = w["da"], w["db"], w["d16"]
+        w["dlogit"].fill_(loss_scale)
+        _lib.check(lib.advh_pool_logreg_bwd(emb.coef.data_ptr(), w["dlogit"].data_ptr(), da.data_ptr(), None, B, T, H, st),
+                   "advh_pool_logreg_bwd")
+        for l in range(nl - 1, -1, -1):
+            bl = w["layers"][l]
+            # x_{l+1} = LN2(s2);  s2 = m + ff2(gelu(ff1(m)));  m = LN1(s1);  s1 = x_l + out(attn(qkv(x_l)))
+            self._ln_bwd(emb.ln2[l], w["s2"][l], da, M, out_f=db, out_h=d16)                 # db = d s2
+            bl["ff2"].run(d16, out_h=w["dI"], dact_src=w["g1"][l])                           # d(pre-GELU)
+            bl["ff1"].run(w["dI"], out_f=da, resid=db)                                        # da = d m
+            self._ln_bwd(emb.ln1[l], w["s1"][l], da, M, out_f=db, out_h=d16)                 # db = d s1
+            bl["out"].run(d16, out_h=w["dctx"])
+            _lib.check(lib.advh_attention_bwd_f16(w["qkv"][l].data_ptr(), w["dctx"].data_ptr(), w["dqkv"].data_ptr(), B, T, H,
+                                                  cfg.num_attention_heads, st), "advh_attention_bwd_f16")
+            bl["qkv"].run(w["dqkv"], out_f=da, resid=db)                                      # da = d x_l
+        self._ln_bwd(emb.enc_ln, w["h1"], da, M, out_f=db)                                    # db = d h1
+        K, Gp = cfg.num_conv_pos_embeddings, cfg.num_conv_pos_embedding_groups
+        _lib.check(lib.advh_posconv_gather(db.data_ptr(), f["xg"].data_ptr(), B, T, H, Gp, K, K // 2 - 1, w["pc"].data_ptr(), st),
+                   "advh_posconv_gather")
+        w["pos"].run(f["xg"], out_f=da, out_h=d16, resid=db)                                  # da = d h0
+        w["proj"].run(d16, out_h=w["dfeatn"])
+        dz = w["dz"]
+        last = nfe - 1
+        body = lambda i: dz[i][C[i]:]                                                         # skip the guard row
+        self._ln_bwd(emb.fp_ln, w["feat"], w["dfeatn"], M, out_h=body(last), dact=w["z"][last], remap=(T, P[last]))
+        for i in range(last, 0, -1):
+            plan, nt = w["fe"][i - 1]
+            a0 = dz[i] if nt == 2 else body(i)
+            plan.run(a0, out_h=body(i - 1), dact_src=w["z"][i - 1] if i > 1 else None)
+        ln0 = emb.fe_ln[0]
+        _lib.check(lib.advh_w2v2_frontend_bwd_group(
+            wave.data_ptr(), wave.stride(0), n_in, B, L, emb.w0.data_ptr(), ln0.g.data_ptr(), f["stats"].data_ptr(),
+            f["norm"].data_ptr(), f["mr"].data_ptr(), body(0).data_ptr(), w["part"].data_ptr(), w["sums"].data_ptr(),
+            body(0).data_ptr(), Ls[0], P[0], C[0], st), "advh_w2v2_frontend_bwd_group")
+        w["g_plan"].run(body(0), out_f=w["g"])
+        dx = torch.empty((B, n_in), dtype=torch.float32, device=wave.device)
+        _lib.check(lib.advh_wave_bwd(w["g"].data_ptr(), wave.data_ptr(), wave.stride(0), n_in, B, L, f["stats"].data_ptr(),
+                                     w["dxh"].data_ptr(), w["wpart"].data_ptr(), 1, 1.0 / loss_scale, dx.data_ptr(), n_in,
+                                     Ls[0], P[0], st), "advh_wave_bwd")
+        return dx

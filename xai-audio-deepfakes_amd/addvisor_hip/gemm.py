@@ -38,6 +38,7 @@ class GemmDesc(C.Structure):
         ("n_div", C.c_int32), ("nz", C.c_int32), ("act", C.c_int32), ("slope", C.c_float),
         ("resid_f32", C.c_int32), ("ktab_identity", C.c_int32),
         ("out_h2", C.c_void_p), ("slope2", C.c_float), ("ph_r", C.c_int32), ("ph_pad", C.c_int32), ("ph_T", C.c_int32),
+        ("out_pre", C.c_void_p), ("dact_src", C.c_void_p),
     ]
 
 
@@ -148,9 +149,14 @@ class GemmPlan:
 
     def run(self, A0: torch.Tensor, A1: Optional[torch.Tensor] = None, *, out_h: Optional[torch.Tensor] = None,
             out_f: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None, stream: Optional[int] = None,
-            out_h2: Optional[torch.Tensor] = None):
+            out_h2: Optional[torch.Tensor] = None, out_pre: Optional[torch.Tensor] = None,
+            dact_src: Optional[torch.Tensor] = None):
         d = self.desc
         d.out_h2 = out_h2.data_ptr() if out_h2 is not None else None
+        d.out_pre = out_pre.data_ptr() if out_pre is not None else None
+        d.dact_src = dact_src.data_ptr() if dact_src is not None else None
+        assert out_pre is None or out_pre.dtype == torch.float16
+        assert dact_src is None or dact_src.dtype == torch.float16
         assert A0.dtype == torch.float16 and A0.is_cuda
         d.A0 = A0.data_ptr()
         d.A1 = A1.data_ptr() if A1 is not None else None

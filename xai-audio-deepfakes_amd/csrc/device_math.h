@@ -18,6 +18,13 @@ __device__ __forceinline__ float fast_erf(float x) {
     return copysignf(r, x);
 }
 
+// d/dx GELU(x) = Phi(x) + x * phi(x)
+__device__ __forceinline__ float gelu_grad(float x) {
+    const float cdf = 0.5f * (1.f + fast_erf(x * 0.70710678118654752440f));
+    const float pdf = 0.3989422804014327f * __builtin_amdgcn_exp2f(-0.72134752044448170f * x * x);
+    return fmaf(x, pdf, cdf);
+}
+
 __device__ __forceinline__ float gelu_fast(float x) { return 0.5f * x * (1.f + fast_erf(x * 0.70710678118654752440f)); }
 
 }  // namespace advh

@@ -63,7 +63,7 @@ __device__ __forceinline__ float load_norm(const float* w, int i, int n, float m
 __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ wave, long stride, int n_in, int L,
                                                        const float2* __restrict__ stats, const float* __restrict__ w0,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                       float2* __restrict__ norm, int T0, int C0) {
+                                                       float2* __restrict__ norm, float2* __restrict__ mr, int T0, int C0) {
     __shared__ double red[4];
     __shared__ double S[K0 + K0 * K0];
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -111,6 +111,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
         if (var < 0) var = 0;
         float sc = gamma[c] * (float)(1.0 / sqrt(var + 1e-5));
         norm[(long)b * C0 + c] = make_float2(sc, beta[c] - (float)m * sc);
+        if (mr) mr[(long)b * C0 + c] = make_float2((float)m, (float)(1.0 / sqrt(var + 1e-5)));     // saved for the backward
     }
 }
 
@@ -163,7 +164,7 @@ using namespace advh;
 
 extern "C" int advh_w2v2_frontend(const float* wave, int64_t wave_stride, int n_in, int B, int L, const float* w0,
                                   const float* bias0, const float* gamma, const float* beta, int mode, int normalize, float* stats_ws,
-                                  float* norm_ws, void* out, int T0, int P0, int C0, advh_stream_t stream) {
+                                  float* norm_ws, float* mr_ws, void* out, int T0, int P0, int C0, advh_stream_t stream) {
     if (!wave || !w0 || !stats_ws || !out || B <= 0 || L < K0 || n_in <= 0 || C0 <= 0 || C0 > 512 || (C0 & 1)) return ADVH_EINVAL;
     if (T0 != (L - K0) / S0 + 1 || P0 < T0 || wave_stride < (n_in < L ? n_in : L)) return ADVH_EINVAL;
     if (mode == 0 && (!gamma || !beta || !norm_ws)) return ADVH_EINVAL;
@@ -172,7 +173,7 @@ extern "C" int advh_w2v2_frontend(const float* wave, int64_t wave_stride, int n_
     hipLaunchKernelGGL(wave_stats_kernel, dim3(B), dim3(256), 0, s, wave, (long)wave_stride, n_in, L, (float2*)stats_ws, normalize);
     if (mode == 0)
         hipLaunchKernelGGL(gn_stats_kernel, dim3(B), dim3(256), 0, s, wave, (long)wave_stride, n_in, L,
-                           (const float2*)stats_ws, w0, gamma, beta, (float2*)norm_ws, T0, C0);
+                           (const float2*)stats_ws, w0, gamma, beta, (float2*)norm_ws, (float2*)mr_ws, T0, C0);
     hipLaunchKernelGGL(conv0_kernel, dim3((P0 + TT - 1) / TT, B), dim3(256), 0, s, wave, (long)wave_stride, n_in, L,
                        (const float2*)stats_ws, w0, bias0, (const float2*)norm_ws, (_Float16*)out, T0, P0, C0, mode);
     return ADVH_LAUNCH_CHECK();

@@ -88,8 +88,17 @@ __device__ __forceinline__ void gemm_epilogue(const advh_gemm_desc& p, f32x4 (&a
             f32x4 v = acc[ni][mi];
             if (ok) {
                 if (bias) { float4 bb = *(const float4*)(bias + n); v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w; }
+                if (p.out_pre) {
+                    f16x4 pv = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+                    *(f16x4*)((_Float16*)p.out_pre + o) = pv;
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], p.act, p.slope);
+                if (p.dact_src) {
+                    f16x4 zz = *(const f16x4*)((const _Float16*)p.dact_src + o);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] *= gelu_grad((float)zz[r]);
+                }
                 if (p.resid) {
                     if (p.resid_f32) {
                         float4 rr = *(const float4*)((const float*)p.resid + o);

@@ -82,7 +82,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const void* __restrict__
 // h [B][T][H] fp32 -> xg [G][B][P][Cg] fp16, P = T + K, data rows [K/2, K/2 + T), zeros elsewhere
 // (the zero padding of the positional Conv1d, modeling_wav2vec2.py:326-379).
 __global__ __launch_bounds__(256) void posconv_gather_kernel(const float* __restrict__ h, _Float16* __restrict__ xg,
-                                                             int B, int T, int H, int G, int K) {
+                                                             int B, int T, int H, int G, int K, int pad_left,
+                                                             const _Float16* __restrict__ dact_src) {
     const int Cg = H / G, P = T + K, c4 = Cg / 4;
     const long total = (long)G * B * P * c4;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -91,10 +92,16 @@ __global__ __launch_bounds__(256) void posconv_gather_kernel(const float* __rest
         int p = (int)(r % P);
         long gb = r / P;
         int b = (int)(gb % B), g = (int)(gb / B);
-        int t = p - K / 2;
+        int t = p - pad_left;
         f16x4 o = {0, 0, 0, 0};
         if (t >= 0 && t < T) {
-            float4 v = *(const float4*)(h + ((long)b * T + t) * H + g * Cg + c);
+            const long src = ((long)b * T + t) * H + g * Cg + c;
+            float4 v = *(const float4*)(h + src);
+            if (dact_src) {                              // backward: gradient w.r.t. the pre-GELU conv output
+                f16x4 z = *(const f16x4*)(dact_src + src);
+                v.x *= gelu_grad((float)z[0]); v.y *= gelu_grad((float)z[1]);
+                v.z *= gelu_grad((float)z[2]); v.w *= gelu_grad((float)z[3]);
+            }
             o = f16x4{(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
         }
         *(f16x4*)(xg + r * Cg + c) = o;
@@ -149,12 +156,14 @@ extern "C" int advh_layernorm(const void* in, int in_is_f32, int64_t in_ld, cons
     return ADVH_LAUNCH_CHECK();
 }
 
-extern "C" int advh_posconv_gather(const float* h, void* xg, int B, int T, int H, int G, int K, advh_stream_t stream) {
-    if (!h || !xg || B <= 0 || T <= 0 || H <= 0 || G <= 0 || H % G || (H / G) % 8 || K <= 0 || K % 2) return ADVH_EINVAL;
+extern "C" int advh_posconv_gather(const float* h, void* xg, int B, int T, int H, int G, int K, int pad_left,
+                                   const void* dact_src, advh_stream_t stream) {
+    if (!h || !xg || B <= 0 || T <= 0 || H <= 0 || G <= 0 || H % G || (H / G) % 8 || K <= 0 || K % 2 || pad_left < 0 || pad_left > K) return ADVH_EINVAL;
     long total = (long)G * B * (T + K) * (H / G / 4);
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(posconv_gather_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, h, (_Float16*)xg, B, T, H, G, K);
+    hipLaunchKernelGGL(posconv_gather_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, h, (_Float16*)xg, B, T, H, G, K, pad_left,
+                       (const _Float16*)dact_src);
     return ADVH_LAUNCH_CHECK();
 }
 
