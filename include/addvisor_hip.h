@@ -237,6 +237,12 @@ int advh_wave_bwd(const float* g, const float* wave, int64_t wave_stride, int n_
                   advh_stream_t stream);
 int advh_scale_rows(const float* x, int x_rows, const float* alpha, float* y, int rows, int64_t n, int accumulate,
                     advh_stream_t stream);
+/* advh_attr_finalize : out = |g| (mode 0, captum Saliency) or x * g (mode 1, InputXGradient / IG with zero baseline).
+ * advh_time_mask     : mask[b] = |attr[b]| / (max|attr[b]| + 1e-8) (captum_saliency.py:136-139) and, if wave is
+ *                      given, wave_in = wave*mask, wave_out = wave*(1-mask) (:141-143); all [B][n] fp32.          */
+int advh_attr_finalize(const float* g, const float* x, float* out, int mode, int64_t total, advh_stream_t stream);
+int advh_time_mask(const float* attr, float* mask, float* wave_in, float* wave_out, const float* wave, int B, int64_t n,
+                   advh_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -89,3 +89,32 @@ def test_input_gradient_base_4s(gpu_device):
     eg, dx = grad_case(syn.base_config(), syn.make_clips(1, 64000), gpu_device, 5e-2)
     again = eg.backward()
     assert torch.equal(dx, again)                                  # deterministic
+
+
+def test_attributions_tiny(gpu_device):
+    """Saliency / InputXGradient / IntegratedGradients vs the oracle (Captum semantics restated)."""
+    from addvisor_hip.attribution import HipAttribution
+    cfg = syn.tiny_config(False)
+    sd = syn.embedder_weights(cfg)
+    coef, icpt = syn.logreg_weights(cfg.hidden_size)
+    model = (sd, cfg, coef, icpt)
+    att = HipAttribution(HipEmbedder(cfg, sd, coef, icpt, gpu_device))
+    w = syn.make_clips(2, 16000, seed=12)
+    wd = w.to(gpu_device)
+    for name, ours, ref in (("saliency", att.saliency(wd), attribution_ref.saliency(w, *model)),
+                            ("ixg", att.input_x_gradient(wd), attribution_ref.input_x_gradient(w, *model)),
+                            ("ig4", att.integrated_gradients(wd, n_steps=4), attribution_ref.integrated_gradients(w, *model, n_steps=4)),
+                            ("ig50", att.integrated_gradients(wd, n_steps=50, internal_batch_size=32),
+                             attribution_ref.integrated_gradients(w, *model, n_steps=50))):
+        err = relerr(ours.cpu(), ref)
+        print(name, "max rel err", err)
+        assert err < 3e-2, name
+    attr = att.integrated_gradients(wd, n_steps=8)
+    mask, win, wout = att.time_mask(attr, wd)
+    ref_mask = attribution_ref.time_mask(attr.cpu())
+    assert torch.allclose(mask.cpu(), ref_mask, atol=1e-6)
+    assert torch.allclose((win + wout).cpu(), w, atol=1e-6) and (mask.amax(1) > 0.999).all()
+    # The classifier normalises every clip (classifier_embedder.py:59-63), so F(alpha * x) = F(x) for alpha > 0:
+    # the path integral of IG is ~0 (not F(x) - F(0): F jumps at alpha = 0).  Size-independent property:
+    ig = att.integrated_gradients(wd, n_steps=50)
+    assert ig.sum(1).abs().max().item() < 5e-2

@@ -60,6 +60,8 @@ SIGNATURES = {
     "advh_w2v2_frontend_bwd_group": (_i, [_p, _i64, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "advh_wave_bwd": (_i, [_p, _p, _i64, _i, _i, _i, _p, _p, _p, _i, _f, _p, _i64, _i, _i, _p]),
     "advh_scale_rows": (_i, [_p, _i, _p, _p, _i, _i64, _i, _p]),
+    "advh_attr_finalize": (_i, [_p, _p, _p, _i, _i64, _p]),
+    "advh_time_mask": (_i, [_p, _p, _p, _p, _p, _i, _i64, _p]),
 }
 
 _lib = None

@@ -361,9 +361,63 @@ __global__ __launch_bounds__(256) void scale_rows_kernel(const float* __restrict
     }
 }
 
+// attr = |g| (mode 0: Saliency), x * g (mode 1: InputXGradient / IntegratedGradients with a zero baseline)
+__global__ __launch_bounds__(256) void attr_finalize_kernel(const float* __restrict__ g, const float* __restrict__ x,
+                                                            float* __restrict__ out, int mode, long total) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256)
+        out[i] = mode == 0 ? fabsf(g[i]) : x[i] * g[i];
+}
+
+// mask[b][:] = |attr[b][:]| / (max|attr[b][:]| + 1e-8)          (captum_saliency.py:136-139), one workgroup per clip
+__global__ __launch_bounds__(1024) void time_mask_kernel(const float* __restrict__ attr, float* __restrict__ mask, long n) {
+    __shared__ float red[16];
+    const float* a = attr + (long)blockIdx.x * n;
+    float m = 0.f;
+    for (long i = threadIdx.x; i < n; i += 1024) m = fmaxf(m, fabsf(a[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = red[0];
+    for (int i = 1; i < 16; ++i) m = fmaxf(m, red[i]);
+    const float d = m + 1e-8f;
+    for (long i = threadIdx.x; i < n; i += 1024) mask[(long)blockIdx.x * n + i] = fabsf(a[i]) / d;
+}
+
+// wave_in = wave * mask, wave_out = wave * (1 - mask)            (captum_saliency.py:141-143)
+__global__ __launch_bounds__(256) void apply_time_mask_kernel(const float* __restrict__ wave, const float* __restrict__ mask,
+                                                              float* __restrict__ win, float* __restrict__ wout, long total) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        float w = wave[i], m = mask[i];
+        win[i] = w * m;
+        wout[i] = w * (1.f - m);
+    }
+}
+
 }  // namespace advh
 
 using namespace advh;
+
+extern "C" int advh_attr_finalize(const float* g, const float* x, float* out, int mode, int64_t total, advh_stream_t stream) {
+    if (!g || !out || (mode == 1 && !x) || (mode != 0 && mode != 1) || total <= 0) return ADVH_EINVAL;
+    long blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(attr_finalize_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, x, out, mode, (long)total);
+    return ADVH_LAUNCH_CHECK();
+}
+
+extern "C" int advh_time_mask(const float* attr, float* mask, float* wave_in, float* wave_out, const float* wave, int B, int64_t n,
+                              advh_stream_t stream) {
+    if (!attr || !mask || B <= 0 || n <= 0 || ((wave_in || wave_out) && (!wave || !wave_in || !wave_out))) return ADVH_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(time_mask_kernel, dim3(B), dim3(1024), 0, s, attr, mask, (long)n);
+    if (wave_in) {
+        long total = (long)B * n, blocks = (total + 255) / 256;
+        if (blocks > 8192) blocks = 8192;
+        hipLaunchKernelGGL(apply_time_mask_kernel, dim3((unsigned)blocks), dim3(256), 0, s, wave, (const float*)mask, wave_in, wave_out, total);
+    }
+    return ADVH_LAUNCH_CHECK();
+}
 
 extern "C" int advh_layernorm_bwd(const void* x, int x_is_f32, const void* dy, int dy_is_f32, const float* gamma,
                                   const float* beta, int gelu_fwd, const float* add, const void* dact_src, float* out_f,
