@@ -81,8 +81,11 @@ def grad_case(cfg, waves, dev, tol):
     return eg, dx
 
 
-def test_input_gradient_tiny(gpu_device):
-    grad_case(syn.tiny_config(False), syn.make_clips(2, 16000, seed=31), gpu_device, 3e-2)
+@pytest.mark.parametrize("variant", ["group_postln", "layer_preln", "layer_preln_depth9"])
+def test_input_gradient_tiny(gpu_device, variant):
+    cfg = {"group_postln": syn.tiny_config(False), "layer_preln": syn.tiny_config(True),
+           "layer_preln_depth9": syn.tiny_config(True, num_hidden_layers=9)}[variant]
+    grad_case(cfg, syn.make_clips(2, 16000, seed=31), gpu_device, 3e-2)
 
 
 def test_input_gradient_base_4s(gpu_device):

@@ -49,8 +49,8 @@ class EmbedderGrad:
     def __init__(self, emb: HipEmbedder):
         self.emb = emb
         self.cfg, self.dev, self.sd = emb.cfg, emb.dev, emb.sd
-        if self.cfg.feat_extract_norm != "group" or self.cfg.do_stable_layer_norm:
-            raise NotImplementedError("input-gradient path is built for the group-norm / post-LN embedder (wav2vec2-base)")
+        self.layer_mode = emb.layer_mode                       # "layer" feature extractor (wav2vec2-large / xls-r)
+        self.stable = self.cfg.do_stable_layer_norm            # pre-LN encoder
         self._ws: Dict[Tuple[int, int], dict] = {}
 
     # ------------------------------------------------------------------ buffers and plans
@@ -71,7 +71,12 @@ class EmbedderGrad:
         w = dict(f=f)
         # forward saves ------------------------------------------------------------------
         w["y"] = [z(B * P[i] * C[i]) for i in range(nfe - 1)]                    # post-GELU outputs of layers 0..5
-        w["z"] = [None] + [z(B * P[i] * C[i]) for i in range(1, nfe - 1)] + [z(M, C[-1])]   # pre-GELU of layers 1..6
+        w["z"] = [z(B * P[0] * C[0]) if self.layer_mode else None]             # pre-norm / pre-GELU outputs of the convs
+        w["z"] += [z(B * P[i] * C[i]) for i in range(1, nfe - 1)] + [z(M, C[-1])]
+        w["dyb"] = z(B * P[0] * C[0]) if self.layer_mode else None
+        w["dfeat"] = z(M, C[-1]) if self.layer_mode else None
+        w["t16"] = z(M, H)
+        w["xf"] = z(M, H, dt=f32)
         w["feat"] = z(M, C[-1])
         w["pc"] = z(M, H)                                                        # pre-GELU positional conv
         w["h1"] = z(M, H, dt=f32)                                                # input of encoder.layer_norm
@@ -140,45 +145,70 @@ class EmbedderGrad:
         f = w["f"]
         st = torch.cuda.current_stream().cuda_stream
         Ls, P, T, M, H = f["Ls"], f["P"], f["T"], f["M"], cfg.hidden_size
-        eps, C, nfe = cfg.layer_norm_eps, cfg.conv_dim, len(f["Ls"])
+        eps, C, nfe, nl = cfg.layer_norm_eps, cfg.conv_dim, len(f["Ls"]), emb.nl
         ln0 = emb.fe_ln[0]
+        lm = self.layer_mode
         _lib.check(lib.advh_w2v2_frontend(
-            wave.data_ptr(), wave.stride(0), n_in, B, L, emb.w0.data_ptr(), None, ln0.g.data_ptr(), ln0.b.data_ptr(), 0, 1,
-            f["stats"].data_ptr(), f["norm"].data_ptr(), f["mr"].data_ptr(), w["y"][0].data_ptr(), Ls[0], P[0], C[0], st),
-            "advh_w2v2_frontend")
+            wave.data_ptr(), wave.stride(0), n_in, B, L, emb.w0.data_ptr(), None if emb.b0 is None else emb.b0.data_ptr(),
+            ln0.g.data_ptr(), ln0.b.data_ptr(), 1 if lm else 0, 1, f["stats"].data_ptr(), f["norm"].data_ptr(), f["mr"].data_ptr(),
+            (w["z"][0] if lm else w["y"][0]).data_ptr(), Ls[0], P[0], C[0], st), "advh_w2v2_frontend")
+        if lm:
+            ln0(w["z"][0], B * P[0], 1e-5, out_h=w["y"][0], gelu=True)
         for i in range(1, nfe):
             last = i == nfe - 1
-            f["fe_plans"][i - 1].run(w["y"][i - 1], out_h=w["feat"] if last else w["y"][i], out_pre=w["z"][i])
+            dst = w["feat"] if last else w["y"][i]
+            if lm:                                         # conv (+bias) -> z_i ; LayerNorm + GELU -> y_i
+                f["fe_plans"][i - 1].run(w["y"][i - 1], out_h=w["z"][i])
+                emb.fe_ln[i](w["z"][i], M if last else B * P[i], 1e-5, out_h=dst, gelu=True)
+            else:
+                f["fe_plans"][i - 1].run(w["y"][i - 1], out_h=dst, out_pre=w["z"][i])
         emb.fp_ln(w["feat"], M, eps, out_h=f["featn"])
         h = f["h"]
         f["proj"].run(f["featn"], out_f=h)
         K, Gp = cfg.num_conv_pos_embeddings, cfg.num_conv_pos_embedding_groups
         _lib.check(lib.advh_posconv_gather(h.data_ptr(), f["xg"].data_ptr(), B, T, H, Gp, K, K // 2, None, st), "advh_posconv_gather")
-        f["pos"].run(f["xg"], out_f=w["h1"], resid=h, out_pre=w["pc"])
         h16 = f["h16"]
-        emb.enc_ln(w["h1"], M, eps, out_f=w["x"][0], out_h=h16)
-        for l in range(emb.nl):
+        if self.stable:
+            f["pos"].run(f["xg"], out_f=w["x"][0], resid=h, out_pre=w["pc"])
+        else:
+            f["pos"].run(f["xg"], out_f=w["h1"], resid=h, out_pre=w["pc"])
+            emb.enc_ln(w["h1"], M, eps, out_f=w["x"][0], out_h=h16)
+        for l in range(nl):
             lay = f["layers"][l]
+            if self.stable:
+                emb.ln1[l](w["x"][l], M, eps, out_h=h16)
             lay["qkv"].run(h16, out_h=w["qkv"][l])
             _lib.check(lib.advh_attention_f16(w["qkv"][l].data_ptr(), f["ctx"].data_ptr(), B, T, H, cfg.num_attention_heads, st),
                        "advh_attention_f16")
-            lay["out"].run(f["ctx"], out_f=w["s1"][l], resid=w["x"][l])
-            emb.ln1[l](w["s1"][l], M, eps, out_f=w["m"][l], out_h=h16)
-            lay["ff1"].run(h16, out_h=f["ffn"], out_pre=w["g1"][l])
-            lay["ff2"].run(f["ffn"], out_f=w["s2"][l], resid=w["m"][l])
-            emb.ln2[l](w["s2"][l], M, eps, out_f=w["x"][l + 1], out_h=h16)
-        _lib.check(lib.advh_pool_logreg(w["x"][emb.nl].data_ptr(), emb.coef.data_ptr(), emb.intercept, f["logit"].data_ptr(),
+            if self.stable:                                # x_{l+1} = m + ffn(LN2(m)),  m = x_l + attn(LN1(x_l))
+                lay["out"].run(f["ctx"], out_f=w["m"][l], resid=w["x"][l])
+                emb.ln2[l](w["m"][l], M, eps, out_h=h16)
+                lay["ff1"].run(h16, out_h=f["ffn"], out_pre=w["g1"][l])
+                lay["ff2"].run(f["ffn"], out_f=w["x"][l + 1], resid=w["m"][l])
+            else:                                          # x_{l+1} = LN2(m + ffn(m)),  m = LN1(x_l + attn(x_l))
+                lay["out"].run(f["ctx"], out_f=w["s1"][l], resid=w["x"][l])
+                emb.ln1[l](w["s1"][l], M, eps, out_f=w["m"][l], out_h=h16)
+                lay["ff1"].run(h16, out_h=f["ffn"], out_pre=w["g1"][l])
+                lay["ff2"].run(f["ffn"], out_f=w["s2"][l], resid=w["m"][l])
+                emb.ln2[l](w["s2"][l], M, eps, out_f=w["x"][l + 1], out_h=h16)
+        final = w["x"][nl]
+        self._final_ln = self.stable and nl == cfg.num_hidden_layers
+        if self._final_ln:
+            emb.enc_ln(w["x"][nl], M, eps, out_f=w["xf"])
+            final = w["xf"]
+        _lib.check(lib.advh_pool_logreg(final.data_ptr(), emb.coef.data_ptr(), emb.intercept, f["logit"].data_ptr(),
                                         f["prob"].data_ptr(), None, B, T, H, st), "advh_pool_logreg")
         self._last = (wave, B, n_in, L)
         return f["logit"].clone().view(B, 1), f["prob"].clone().view(B, 1)
 
     # ------------------------------------------------------------------ backward
-    def _ln_bwd(self, ln, x, dy, M, out_f=None, out_h=None, add=None, dact=None, remap=(0, 0)):
+    def _ln_bwd(self, ln, x, dy, M, out_f=None, out_h=None, add=None, dact=None, remap=(0, 0), gelu=False, eps=None):
         _lib.check(_lib.lib().advh_layernorm_bwd(
             x.data_ptr(), int(x.dtype == torch.float32), dy.data_ptr(), int(dy.dtype == torch.float32), ln.g.data_ptr(),
-            ln.b.data_ptr(), 0, None if add is None else add.data_ptr(), None if dact is None else dact.data_ptr(),
+            ln.b.data_ptr(), int(gelu), None if add is None else add.data_ptr(), None if dact is None else dact.data_ptr(),
             None if out_f is None else out_f.data_ptr(), None if out_h is None else out_h.data_ptr(), M, ln.C,
-            self.cfg.layer_norm_eps, remap[0], remap[1], torch.cuda.current_stream().cuda_stream), "advh_layernorm_bwd")
+            self.cfg.layer_norm_eps if eps is None else eps, remap[0], remap[1], torch.cuda.current_stream().cuda_stream),
+            "advh_layernorm_bwd")
 
     def backward(self, loss_scale: float = 4096.0) -> torch.Tensor:
         """d logit / d wave for the clips of the last ``forward`` call: ``[B, n_in]`` fp32."""
@@ -189,40 +219,64 @@ class EmbedderGrad:
         st = torch.cuda.current_stream().cuda_stream
         Ls, P, T, M, H = f["Ls"], f["P"], f["T"], f["M"], cfg.hidden_size
         C, nfe, nl = cfg.conv_dim, len(f["Ls"]), emb.nl
-        da, db, d16 = w["da"], w["db"], w["d16"]
+        da, db, d16, t16 = w["da"], w["db"], w["d16"], w["t16"]
+        heads = cfg.num_attention_heads
         w["dlogit"].fill_(loss_scale)
-        _lib.check(lib.advh_pool_logreg_bwd(emb.coef.data_ptr(), w["dlogit"].data_ptr(), da.data_ptr(), None, B, T, H, st),
+        _lib.check(lib.advh_pool_logreg_bwd(emb.coef.data_ptr(), w["dlogit"].data_ptr(), da.data_ptr(), d16.data_ptr(), B, T, H, st),
                    "advh_pool_logreg_bwd")
+        if self._final_ln:
+            self._ln_bwd(emb.enc_ln, w["x"][nl], da, M, out_f=db, out_h=d16)
+            da, db = db, da
         for l in range(nl - 1, -1, -1):
             bl = w["layers"][l]
-            # x_{l+1} = LN2(s2);  s2 = m + ff2(gelu(ff1(m)));  m = LN1(s1);  s1 = x_l + out(attn(qkv(x_l)))
-            self._ln_bwd(emb.ln2[l], w["s2"][l], da, M, out_f=db, out_h=d16)                 # db = d s2
-            bl["ff2"].run(d16, out_h=w["dI"], dact_src=w["g1"][l])                           # d(pre-GELU)
-            bl["ff1"].run(w["dI"], out_f=da, resid=db)                                        # da = d m
-            self._ln_bwd(emb.ln1[l], w["s1"][l], da, M, out_f=db, out_h=d16)                 # db = d s1
-            bl["out"].run(d16, out_h=w["dctx"])
-            _lib.check(lib.advh_attention_bwd_f16(w["qkv"][l].data_ptr(), w["dctx"].data_ptr(), w["dqkv"].data_ptr(), B, T, H,
-                                                  cfg.num_attention_heads, st), "advh_attention_bwd_f16")
-            bl["qkv"].run(w["dqkv"], out_f=da, resid=db)                                      # da = d x_l
-        self._ln_bwd(emb.enc_ln, w["h1"], da, M, out_f=db)                                    # db = d h1
+            if self.stable:                                # da = d x_{l+1} (fp32), d16 its fp16 copy
+                bl["ff2"].run(d16, out_h=w["dI"], dact_src=w["g1"][l])
+                bl["ff1"].run(w["dI"], out_h=t16)                                             # d LN2(m)
+                self._ln_bwd(emb.ln2[l], w["m"][l], t16, M, out_f=db, out_h=d16, add=da)      # db = d m
+                bl["out"].run(d16, out_h=w["dctx"])
+                _lib.check(lib.advh_attention_bwd_f16(w["qkv"][l].data_ptr(), w["dctx"].data_ptr(), w["dqkv"].data_ptr(), B, T, H,
+                                                      heads, st), "advh_attention_bwd_f16")
+                bl["qkv"].run(w["dqkv"], out_h=t16)                                           # d LN1(x_l)
+                self._ln_bwd(emb.ln1[l], w["x"][l], t16, M, out_f=da, out_h=d16, add=db)      # da = d x_l
+            else:
+                self._ln_bwd(emb.ln2[l], w["s2"][l], da, M, out_f=db, out_h=d16)              # db = d s2
+                bl["ff2"].run(d16, out_h=w["dI"], dact_src=w["g1"][l])                        # d(pre-GELU)
+                bl["ff1"].run(w["dI"], out_f=da, resid=db)                                    # da = d m
+                self._ln_bwd(emb.ln1[l], w["s1"][l], da, M, out_f=db, out_h=d16)              # db = d s1
+                bl["out"].run(d16, out_h=w["dctx"])
+                _lib.check(lib.advh_attention_bwd_f16(w["qkv"][l].data_ptr(), w["dctx"].data_ptr(), w["dqkv"].data_ptr(), B, T, H,
+                                                      heads, st), "advh_attention_bwd_f16")
+                bl["qkv"].run(w["dqkv"], out_f=da, resid=db)                                  # da = d x_l
+        if not self.stable:
+            self._ln_bwd(emb.enc_ln, w["h1"], da, M, out_f=db)                                # d h1
+            da, db = db, da
         K, Gp = cfg.num_conv_pos_embeddings, cfg.num_conv_pos_embedding_groups
-        _lib.check(lib.advh_posconv_gather(db.data_ptr(), f["xg"].data_ptr(), B, T, H, Gp, K, K // 2 - 1, w["pc"].data_ptr(), st),
+        _lib.check(lib.advh_posconv_gather(da.data_ptr(), f["xg"].data_ptr(), B, T, H, Gp, K, K // 2 - 1, w["pc"].data_ptr(), st),
                    "advh_posconv_gather")
-        w["pos"].run(f["xg"], out_f=da, out_h=d16, resid=db)                                  # da = d h0
+        w["pos"].run(f["xg"], out_f=db, out_h=d16, resid=da)                                  # d h0
         w["proj"].run(d16, out_h=w["dfeatn"])
         dz = w["dz"]
         last = nfe - 1
         body = lambda i: dz[i][C[i]:]                                                         # skip the guard row
-        self._ln_bwd(emb.fp_ln, w["feat"], w["dfeatn"], M, out_h=body(last), dact=w["z"][last], remap=(T, P[last]))
+        if self.layer_mode:
+            self._ln_bwd(emb.fp_ln, w["feat"], w["dfeatn"], M, out_h=w["dfeat"])
+            self._ln_bwd(emb.fe_ln[last], w["z"][last], w["dfeat"], M, out_h=body(last), remap=(T, P[last]), gelu=True, eps=1e-5)
+        else:
+            self._ln_bwd(emb.fp_ln, w["feat"], w["dfeatn"], M, out_h=body(last), dact=w["z"][last], remap=(T, P[last]))
         for i in range(last, 0, -1):
             plan, nt = w["fe"][i - 1]
             a0 = dz[i] if nt == 2 else body(i)
-            plan.run(a0, out_h=body(i - 1), dact_src=w["z"][i - 1] if i > 1 else None)
-        ln0 = emb.fe_ln[0]
-        _lib.check(lib.advh_w2v2_frontend_bwd_group(
-            wave.data_ptr(), wave.stride(0), n_in, B, L, emb.w0.data_ptr(), ln0.g.data_ptr(), f["stats"].data_ptr(),
-            f["norm"].data_ptr(), f["mr"].data_ptr(), body(0).data_ptr(), w["part"].data_ptr(), w["sums"].data_ptr(),
-            body(0).data_ptr(), Ls[0], P[0], C[0], st), "advh_w2v2_frontend_bwd_group")
+            if self.layer_mode:
+                plan.run(a0, out_h=w["dyb"])
+                self._ln_bwd(emb.fe_ln[i - 1], w["z"][i - 1], w["dyb"], B * P[i - 1], out_h=body(i - 1), gelu=True, eps=1e-5)
+            else:
+                plan.run(a0, out_h=body(i - 1), dact_src=w["z"][i - 1] if i > 1 else None)
+        if not self.layer_mode:
+            ln0 = emb.fe_ln[0]
+            _lib.check(lib.advh_w2v2_frontend_bwd_group(
+                wave.data_ptr(), wave.stride(0), n_in, B, L, emb.w0.data_ptr(), ln0.g.data_ptr(), f["stats"].data_ptr(),
+                f["norm"].data_ptr(), f["mr"].data_ptr(), body(0).data_ptr(), w["part"].data_ptr(), w["sums"].data_ptr(),
+                body(0).data_ptr(), Ls[0], P[0], C[0], st), "advh_w2v2_frontend_bwd_group")
         w["g_plan"].run(body(0), out_f=w["g"])
         dx = torch.empty((B, n_in), dtype=torch.float32, device=wave.device)
         _lib.check(lib.advh_wave_bwd(w["g"].data_ptr(), wave.data_ptr(), wave.stride(0), n_in, B, L, f["stats"].data_ptr(),
