@@ -17,9 +17,10 @@ def model_logit(waves, emb_sd, emb_cfg, coef, intercept):
 
 
 def input_gradient(waves, emb_sd, emb_cfg, coef, intercept):
-    x = waves.clone().detach().requires_grad_(True)
-    out = model_logit(x, emb_sd, emb_cfg, coef, intercept)
-    (g,) = torch.autograd.grad(out.sum(), x)
+    with torch.enable_grad():
+        x = waves.clone().detach().requires_grad_(True)
+        out = model_logit(x, emb_sd, emb_cfg, coef, intercept)
+        (g,) = torch.autograd.grad(out.sum(), x)
     return g
 
 

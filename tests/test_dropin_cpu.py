@@ -17,9 +17,11 @@ def test_modules_import_without_gpu_or_network():
     runtime.reset()
     import addvisor
     import audioprocessor
+    import captum_saliency
     import classifier_embedder
     import LMAC_metrics
     import loss_function
+    assert hasattr(captum_saliency, "Wav2vec2LogReg") and hasattr(captum_saliency, "compute_camptum_saliency_metrics")
     assert addvisor.ADDvisor is addvisor.UNet
     sig = inspect.signature(audioprocessor.AudioProcessor.__init__)
     assert [p for p in sig.parameters][1:] == ["sampling_rate", "n_fft", "hop_length", "win_length", "n_mels", "audio_length"]

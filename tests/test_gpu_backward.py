@@ -25,10 +25,11 @@ def test_layernorm_bwd(gpu_device):
     dy = torch.randn(M, C, generator=g)
     add = torch.randn(M, C, generator=g)
     for gelu in (0, 1):
-        y = F.layer_norm(x, (C,), gamma, beta, 1e-5)
-        if gelu:
-            y = F.gelu(y)
-        (ref,) = torch.autograd.grad(y, x, dy)
+        with torch.enable_grad():
+            y = F.layer_norm(x, (C,), gamma, beta, 1e-5)
+            if gelu:
+                y = F.gelu(y)
+            (ref,) = torch.autograd.grad(y, x, dy)
         d = gpu_device
         out = torch.empty(M, C, device=d)
         xd, dyd, gd, bd, ad = x.detach().to(d), dy.to(d), gamma.to(d), beta.to(d), add.to(d)     # keep the operands alive
@@ -47,11 +48,12 @@ def test_attention_bwd(gpu_device, T, heads, D):
     B, H = 2, heads * D
     qkv = (torch.randn(B * T, 3 * H, generator=g) * 0.7).half()
     dctx = (torch.randn(B * T, H, generator=g)).half()
-    x = qkv.float().requires_grad_(True)
-    q, k, v = [t.view(B, T, heads, D).transpose(1, 2) for t in x.split(H, dim=1)]
-    a = torch.softmax(q @ k.transpose(2, 3) * D ** -0.5, -1)
-    ctx = (a @ v).transpose(1, 2).reshape(B * T, H)
-    (ref,) = torch.autograd.grad(ctx, x, dctx.float())
+    with torch.enable_grad():
+        x = qkv.float().requires_grad_(True)
+        q, k, v = [t.view(B, T, heads, D).transpose(1, 2) for t in x.split(H, dim=1)]
+        a = torch.softmax(q @ k.transpose(2, 3) * D ** -0.5, -1)
+        ctx = (a @ v).transpose(1, 2).reshape(B * T, H)
+        (ref,) = torch.autograd.grad(ctx, x, dctx.float())
     d = gpu_device
     out = torch.zeros(B * T, 3 * H, dtype=torch.float16, device=d)
     qd, dd = qkv.to(d), dctx.to(d)
@@ -71,7 +73,8 @@ def grad_case(cfg, waves, dev, tol):
     logit, _ = eg.forward(waves.to(dev))
     dx = eg.backward()
     ref = attribution_ref.input_gradient(waves, sd, cfg, coef, icpt)
-    ref_logit = attribution_ref.model_logit(waves, sd, cfg, coef, icpt).detach()
+    with torch.no_grad():
+        ref_logit = attribution_ref.model_logit(waves, sd, cfg, coef, icpt)
     assert (logit.cpu() - ref_logit).abs().max().item() < 1e-2
     assert torch.isfinite(dx).all()
     err = relerr(dx.cpu(), ref)

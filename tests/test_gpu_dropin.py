@@ -97,3 +97,26 @@ def test_run_addvisor_metrics_synthetic_dataset(gpu_device, capsys):
     ref = lmac_ref.explain(DS().w, sd, cfg, clf.coef_, clf.intercept_, syn.unet_weights(), audio_length=1)
     r = lmac_ref.lmac_summary(ref["predictions"], ref["theta_out"], ref["masked_predictions"])
     assert abs(m["faithfulness"] - r["faithfulness"]) < 1e-2 and abs(m["AD"] - r["AD"]) < 2.0
+
+
+def test_captum_compatible_api(gpu_device):
+    """``from captum.attr import ...`` resolves to the HIP attribution path (captum_saliency.py:3, 116-135)."""
+    import captum_saliency as cs
+    from captum.attr import InputXGradient, IntegratedGradients, Saliency
+    from oracle import attribution_ref
+    model = cs.Wav2vec2LogReg(cs.audioprocessor, cs.TorchLogReg()).to(gpu_device)
+    w = syn.make_clips(2, 16000, seed=12)
+    cfg, sd = runtime.embedder_config_and_weights()
+    clf = runtime.classifier()
+    m = (sd, cfg, clf.coef_, clf.intercept_)
+    x = w.to(gpu_device).clone().detach().requires_grad_(True)        # as captum_saliency.py:129
+    sal = Saliency(model).attribute(inputs=x, target=None)
+    ixg = InputXGradient(model).attribute(inputs=x, target=None)
+    ig = IntegratedGradients(model).attribute(inputs=x, target=None, n_steps=8)
+    rel = lambda a, b: ((a.cpu() - b).abs().max() / b.abs().max()).item()
+    assert rel(sal, attribution_ref.saliency(w, *m)) < 3e-2
+    assert rel(ixg, attribution_ref.input_x_gradient(w, *m)) < 3e-2
+    assert rel(ig, attribution_ref.integrated_gradients(w, *m, n_steps=8)) < 3e-2
+    assert (model(w.to(gpu_device)).cpu() - attribution_ref.model_logit(w, *m).detach()).abs().max() < 1e-2
+    p, t, o = cs.explain_waves(model, w, "saliency")
+    assert p.shape == t.shape == o.shape == (2, 1)
