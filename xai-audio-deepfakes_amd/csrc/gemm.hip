@@ -35,6 +35,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BK = 64;          // halfs per K-step = 8 chunks of 16 B
 
+// ds_read_b128 the compiler does not track (see the pipelined kernel) and the matching counted wait
+#define DS_READ128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#define LGKM_WAIT(n) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(n) : "memory")
+
 __device__ __forceinline__ float apply_act(float x, int act, float slope) {
     if (act == ADVH_ACT_GELU) return gelu_fast(x);
     if (act == ADVH_ACT_LEAKY) return x > 0.f ? x : slope * x;
@@ -301,6 +305,8 @@ __global__ __launch_bounds__(512) void gemm_f16_pipe_kernel(const advh_gemm_desc
         offA[kk] = ((wm * TM + fr) * 8 + c) * 16;
         offB[kk] = BM * BK * 2 + ((wn * TN + fr) * 8 + c) * 16;
     }
+    const unsigned lds0 = (unsigned)(unsigned long)LDS_PTR(dsmem);
+    const unsigned uoffA[2] = {(unsigned)offA[0], (unsigned)offA[1]}, uoffB[2] = {(unsigned)offB[0], (unsigned)offB[1]};
 
     f32x4 acc[NI][MI];
 #pragma unroll
@@ -310,22 +316,25 @@ __global__ __launch_bounds__(512) void gemm_f16_pipe_kernel(const advh_gemm_desc
 
     const int nk = p.Ktot / BK;
     const int* ktab = p.ktab;
-    auto issue = [&](int kt) {
-        // identity tables (plain GEMM / conv1d rows) need no lookup; otherwise a cached 4-byte load
-        const int kq = p.ktab_identity ? kt * 8 + q : ktab[kt * 8 + q];
+    // one 16-byte-per-lane DMA piece `i` (0 <= i < NA + NB) of K-tile kt; kq = its A chunk offset
+    auto issue_piece = [&](int kt, int kq, int i) {
         char* st = dsmem + (kt % STAGES) * STAGE;
-        const bool s1 = kq < 0;
-        const unsigned ko = (unsigned)kq & 0x7fffffffu;
-        const _Float16* base = s1 ? A1 : A0;
-#pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            const _Float16* g = base + ((unsigned long)((s1 ? rb1[i] : rb0[i]) + ko)) * 8;
+        if (i < NA) {
+            const bool s1 = kq < 0;
+            const unsigned ko = (unsigned)kq & 0x7fffffffu;
+            const _Float16* g = (s1 ? A1 : A0) + ((unsigned long)((s1 ? rb1[i] : rb0[i]) + ko)) * 8;
             __builtin_amdgcn_global_load_lds(GLOBAL_PTR(g), LDS_PTR(st + (wv * 64 + 512 * i) * 16), 16, 0, 0);
+        } else {
+            const int j = i - NA;
+            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(wrow[j] + kt * BK),
+                                             LDS_PTR(st + BM * BK * 2 + (wv * 64 + 512 * j) * 16), 16, 0, 0);
         }
+    };
+    auto tile_kq = [&](int kt) { return p.ktab_identity ? kt * 8 + q : ktab[kt * 8 + q]; };
+    auto issue = [&](int kt) {
+        const int kq = tile_kq(kt);
 #pragma unroll
-        for (int i = 0; i < NB; ++i)
-            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(wrow[i] + kt * BK),
-                                             LDS_PTR(st + BM * BK * 2 + (wv * 64 + 512 * i) * 16), 16, 0, 0);
+        for (int i = 0; i < NA + NB; ++i) issue_piece(kt, kq, i);
     };
     // prologue: STAGES-1 tiles in flight
 #pragma unroll
@@ -337,20 +346,51 @@ __global__ __launch_bounds__(512) void gemm_f16_pipe_kernel(const advh_gemm_desc
         else if (STAGES == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + NB) : "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (NA + NB)) : "memory");
         __builtin_amdgcn_s_barrier();                          // ... for every wavefront; stage (kt-1)%STAGES is free
-        if (kt + STAGES - 1 < nk) issue(kt + STAGES - 1);      // in flight under the next STAGES-1 compute phases
-        const char* st = dsmem + (kt % STAGES) * STAGE;
+        // the DMA of tile kt+STAGES-1 is issued piecewise between the MFMA groups below (a wavefront pays ~100
+        // cycles of issue per LDS-DMA piece: spread out, they overlap the partner wavefront's MFMAs)
+        const bool more = kt + STAGES - 1 < nk;
+        const int kq_next = more ? tile_kq(kt + STAGES - 1) : 0;
+        // Fragment software pipeline with hand-counted LDS waits.  The A fragments of m-pair g+1 (and, at the end
+        // of a 32-deep half, the next half's B fragments) are requested before the 2*NI MFMAs of m-pair g issue.
+        // hipcc waits lgkmcnt(0) at every first use, which would also wait for the reads just issued for the NEXT
+        // group; the ds_reads are therefore inline asm (invisible to its scoreboard) and each group waits with the
+        // exact count of younger reads allowed to stay in flight (cdna_hip_programming.md §5.7 form (iii)).
+        const unsigned sbase = lds0 + (kt % STAGES) * STAGE;
+        f16x8 b[2][NI], a[2][2];
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            f16x8 a[MI], b[NI];
+        for (int ni = 0; ni < NI; ++ni) DS_READ128(b[0][ni], sbase + uoffB[0], ni * 2048);
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) b[ni] = *(const f16x8*)(st + offB[kk] + ni * 16 * 128);
+        for (int e = 0; e < 2; ++e) DS_READ128(a[0][e], sbase + uoffA[0], e * 2048);
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi) a[mi] = *(const f16x8*)(st + offA[kk] + mi * 16 * 128);
+        for (int step = 0; step < MI; ++step) {            // step = kk * (MI/2) + pair
+            const int kk = step / (MI / 2), pr = step % (MI / 2), cur = step & 1, nxt = cur ^ 1;
+            if (step + 1 < MI) {
+                const int kk2 = (step + 1) / (MI / 2), pr2 = (step + 1) % (MI / 2);
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
+                for (int e = 0; e < 2; ++e) DS_READ128(a[nxt][e], sbase + uoffA[kk2], (2 * pr2 + e) * 2048);
+                if (pr2 == 0) {
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) DS_READ128(b[1][ni], sbase + uoffB[1], ni * 2048);
+                    LGKM_WAIT(2 + NI);
+                } else {
+                    LGKM_WAIT(2);
+                }
+            } else {
+                LGKM_WAIT(0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni)
-                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[ni], a[mi], acc[ni][mi], 0, 0, 0);
+                    acc[ni][2 * pr + e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[kk][ni], a[cur][e], acc[ni][2 * pr + e], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) {
+                constexpr int PER = (NA + NB + MI - 1) / MI;
+#pragma unroll
+                for (int i = step * PER; i < (step + 1) * PER && i < NA + NB; ++i) issue_piece(kt + STAGES - 1, kq_next, i);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     gemm_epilogue<MI, NI>(p, acc, m0 + wm * TM, n0 + wn * TN, fr, fq, z);
