@@ -41,6 +41,9 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="multi-rank dry run on ONE GPU: gloo backend, every rank on cuda:0 (checks the sharding / "
+                         "gather / timing logic where no multi-GPU node is available; not a measurement)")
     ap.add_argument("--no-tune", action="store_true", help="keep the default 128x128 GEMM tile everywhere")
     ap.add_argument("--cpu-clips", type=int, default=4)
     ap.add_argument("--cpu-threads", type=int, default=16, help="host threads for the CPU baseline (a 1-GPU box owns 16)")
@@ -53,13 +56,14 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = 0 if args.rehearse else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)       # "nccl" is RCCL on ROCm
+        dist.init_process_group("gloo" if args.rehearse else "nccl", rank=rank, world_size=world)   # "nccl" = RCCL on ROCm
 
     from addvisor_hip import gemm as G, pipeline as P, synthetic as syn
     torch.set_grad_enabled(False)
@@ -96,13 +100,16 @@ def main():
         out = pipe.explain(batches[i % n_batches])
         probs.append(torch.cat([out["predictions"], out["theta_out"], out["masked_predictions"]], 1))
     local = torch.cat(probs, 0)
-    allp = P.gather_probabilities(local, local.shape[0] * world)           # the one exchange step
-    metrics = P.lmac_metrics(allp[:, 0], allp[:, 1], allp[:, 2])
+    if args.rehearse and world > 1:                                        # gloo has no CUDA all_gather: stage through the host
+        allp = P.gather_probabilities(local.cpu(), local.shape[0] * world).to(dev)
+    else:
+        allp = P.gather_probabilities(local, local.shape[0] * world)       # the one exchange step (RCCL)
+    metrics = P.lmac_metrics(allp[:, 0].contiguous(), allp[:, 1].contiguous(), allp[:, 2].contiguous())
     barrier()
     elapsed = time.perf_counter() - t0
     G.PROFILE.enabled = False
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
