@@ -43,6 +43,10 @@ const char* advh_version(void);
  * any stream capture.  Idempotent. */
 int advh_init(void);
 
+/* Tuning knobs (process-wide, not thread-safe; set before launching work):
+ *   "stft_frames_per_workgroup" = 8 (default) | 16 : STFT / ISTFT frames per workgroup. */
+int advh_set_option(const char* name, int value);
+
 /* ---------------------------------------------------------------------------------------------
  * STFT  -- replaces AudioProcessor.compute_stft (audioprocessor.py:82-112):
  *   pad/crop to L samples, torch.stft(n_fft=1024, hop, win, window=None|window, center=True,

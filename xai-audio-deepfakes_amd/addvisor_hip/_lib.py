@@ -37,6 +37,7 @@ _p, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 SIGNATURES = {
     "advh_version": (C.c_char_p, []),
     "advh_init": (_i, []),
+    "advh_set_option": (_i, [C.c_char_p, _i]),
     "advh_stft_forward": (_i, [_p, _i64, _i, _i, _i, _i, _i, _p, _p, _p, _p, _i, _p]),
     "advh_istft_masked": (_i, [_p, _p, _p, _i, _i, _i, _p, _p, _i64, _i, _i, _i, _i, _i, _p, _p]),
     "advh_istft_c64": (_i, [_p, _p, _i64, _i, _i, _i, _i, _i, _p, _p]),

@@ -22,7 +22,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <int NT, int D>
 __global__ __launch_bounds__(256) void attention_kernel(const _Float16* __restrict__ qkv, _Float16* __restrict__ ctx,
                                                         int T, int H, float scale) {
-    constexpr int NKEY = NT * 16, CH = D / 8, VP = NKEY + 8, NS = (NT + 1) / 2, KK = D / 32, DT = D / 16;
+    constexpr int NKEY = NT * 16, CH = D / 8, VP = NKEY + 64 /* row pitch incl. the per-8-rows skew that spreads the transposing stores over the banks */, NS = (NT + 1) / 2, KK = D / 32, DT = D / 16;
     __shared__ __attribute__((aligned(16))) _Float16 Ks[NKEY * D];
     __shared__ __attribute__((aligned(16))) _Float16 Vt[D * VP];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const _Float16* __restri
         }
         *(f16x8*)(Ks + key * D + ((c ^ (key & (CH - 1))) * 8)) = kv;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) Vt[(c * 8 + j) * VP + key] = vv[j];
+        for (int j = 0; j < 8; ++j) Vt[(c * 8 + j) * VP + c * 8 + key] = vv[j];
     }
     __syncthreads();
 
@@ -94,19 +94,25 @@ __global__ __launch_bounds__(256) void attention_kernel(const _Float16* __restri
                 pf[ss][4 + r] = (2 * ss + 1 < NT) ? (_Float16)(s[(2 * ss + 1 < NT) ? 2 * ss + 1 : 0][r] * inv) : (_Float16)0.f;
             }
         }
+        // O^T = V^T P^T, key steps outermost so only one step's V^T fragments are live at a time
+        f32x4 o[DT];
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
-            f32x4 o = {0.f, 0.f, 0.f, 0.f};
+        for (int dt = 0; dt < DT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int ss = 0; ss < NS; ++ss) {
-                const _Float16* vr = Vt + (dt * 16 + fr) * VP + ss * 32 + g * 4;
+        for (int ss = 0; ss < NS; ++ss) {
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const _Float16* vr = Vt + (dt * 16 + fr) * VP + ((dt * 16 + fr) >> 3) * 8 + ss * 32 + g * 4;
                 f16x4 lo = *(const f16x4*)vr;
                 f16x4 hi = (2 * ss + 1 < NT) ? *(const f16x4*)(vr + 16) : f16x4{0, 0, 0, 0};
                 f16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                o = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[ss], o, 0, 0, 0);
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[ss], o[dt], 0, 0, 0);
             }
-            if (qrow < T) {
-                f16x4 hv = {(_Float16)o[0], (_Float16)o[1], (_Float16)o[2], (_Float16)o[3]};
+        }
+        if (qrow < T) {
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                f16x4 hv = {(_Float16)o[dt][0], (_Float16)o[dt][1], (_Float16)o[dt][2], (_Float16)o[dt][3]};
                 *(f16x4*)(ctx + ((long)b * T + qrow) * H + head * D + dt * 16 + g * 4) = hv;
             }
         }

@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
 template <int NT, int D>
 __global__ __launch_bounds__(256) void attention_bwd_kernel(const _Float16* __restrict__ qkv, const _Float16* __restrict__ dctx,
                                                             _Float16* __restrict__ dqkv, int T, int H, float scale) {
-    constexpr int NKEY = NT * 16, CH = D / 8, VP = NKEY + 8, NS = (NT + 1) / 2, KK = D / 32, DT = D / 16;
+    constexpr int NKEY = NT * 16, CH = D / 8, VP = NKEY + 64, NS = (NT + 1) / 2, KK = D / 32, DT = D / 16;
     constexpr int ROWB = NKEY * D, TRB = D * VP;
     // LDS: pass A uses K | V (row-major, swizzled) | Kt ; pass B re-uses the space for Qt | dOt ; stats stay.
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const _Float16* __re
         *(f16x8*)(Ks + key * D + sw) = kv;
         *(f16x8*)(Vs + key * D + sw) = vv;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) Kt[(c * 8 + j) * VP + key] = kv[j];
+        for (int j = 0; j < 8; ++j) Kt[(c * 8 + j) * VP + c * 8 + key] = kv[j];
     }
     __syncthreads();
 
@@ -234,19 +234,24 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const _Float16* __re
                                                                 (dp[(2 * ss + 1 < NT) ? 2 * ss + 1 : 0][r] - del) * scale)
                                                    : (_Float16)0.f;
             }
+        f32x4 o[DT];
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
-            f32x4 o = {0.f, 0.f, 0.f, 0.f};
+        for (int dt = 0; dt < DT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int ss = 0; ss < NS; ++ss) {
-                const _Float16* kr = Kt + (dt * 16 + fr) * VP + ss * 32 + g * 4;
+        for (int ss = 0; ss < NS; ++ss) {
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const _Float16* kr = Kt + (dt * 16 + fr) * VP + ((dt * 16 + fr) >> 3) * 8 + ss * 32 + g * 4;
                 f16x4 lo = *(const f16x4*)kr;
                 f16x4 hi = (2 * ss + 1 < NT) ? *(const f16x4*)(kr + 16) : f16x4{0, 0, 0, 0};
                 f16x8 kf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                o = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, dsf[ss], o, 0, 0, 0);             // dQ^T [d][q]
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, dsf[ss], o[dt], 0, 0, 0);     // dQ^T [d][q]
             }
-            if (qrow < T) {
-                f16x4 hv = {(_Float16)o[0], (_Float16)o[1], (_Float16)o[2], (_Float16)o[3]};
+        }
+        if (qrow < T) {
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                f16x4 hv = {(_Float16)o[dt][0], (_Float16)o[dt][1], (_Float16)o[dt][2], (_Float16)o[dt][3]};
                 *(f16x4*)(dbase + (long)qrow * ld + dt * 16 + g * 4) = hv;
             }
         }
@@ -262,7 +267,7 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const _Float16* __re
             ov = *(const f16x8*)(dob + (long)row * H + c * 8);
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { Qt[(c * 8 + j) * VP + row] = qv[j]; dOt[(c * 8 + j) * VP + row] = ov[j]; }
+        for (int j = 0; j < 8; ++j) { Qt[(c * 8 + j) * VP + c * 8 + row] = qv[j]; dOt[(c * 8 + j) * VP + c * 8 + row] = ov[j]; }
     }
     __syncthreads();
     for (int kt = wv; kt * 16 < T; kt += 4) {
@@ -309,8 +314,8 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const _Float16* __re
             }
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
-                const _Float16* orow = dOt + (dt * 16 + fr) * VP + ss * 32 + g * 4;
-                const _Float16* qrow_ = Qt + (dt * 16 + fr) * VP + ss * 32 + g * 4;
+                const _Float16* orow = dOt + (dt * 16 + fr) * VP + ((dt * 16 + fr) >> 3) * 8 + ss * 32 + g * 4;
+                const _Float16* qrow_ = Qt + (dt * 16 + fr) * VP + ((dt * 16 + fr) >> 3) * 8 + ss * 32 + g * 4;
                 f16x4 olo = *(const f16x4*)orow, qlo = *(const f16x4*)qrow_;
                 f16x4 ohi = (2 * ss + 1 < NT) ? *(const f16x4*)(orow + 16) : f16x4{0, 0, 0, 0};
                 f16x4 qhi = (2 * ss + 1 < NT) ? *(const f16x4*)(qrow_ + 16) : f16x4{0, 0, 0, 0};
@@ -443,7 +448,7 @@ extern "C" int advh_layernorm_bwd(const void* x, int x_is_f32, const void* dy, i
 
 template <int NT, int D>
 static int launch_att_bwd(const void* qkv, const void* dctx, void* dqkv, int B, int T, int H, int heads, float scale, hipStream_t s) {
-    constexpr int NKEY = NT * 16, VP = NKEY + 8;
+    constexpr int NKEY = NT * 16, VP = NKEY + 64;
     const size_t lds = (size_t)(2 * NKEY * D + D * VP) * 2 + 3 * NKEY * 4;
     static bool attr_done = false;
     if (!attr_done) {

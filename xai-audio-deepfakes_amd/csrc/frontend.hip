@@ -117,7 +117,10 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
 
 // out[b][t][c] = GELU(conv * scale + shift)   (mode 0, "group")   or   conv + bias   (mode 1, raw: the
 // LayerNorm + GELU of the "layer" feature extractor follow as a row kernel).  Rows t in [T0, P0) = 0.
+// A thread owns 8 consecutive channels (their 80 taps live in registers) and walks the tile's frames, so every
+// store is one 16-byte vector and a wavefront writes 1 KiB contiguous per frame (C0 = 512: 64 lanes x 8 ch).
 constexpr int TT = 64;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ wave, long stride, int n_in, int L,
                                                     const float2* __restrict__ stats, const float* __restrict__ w0,
                                                     const float* __restrict__ bias, const float2* __restrict__ norm,
@@ -129,32 +132,37 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ wa
     const float2 st = stats[b];
     for (int i = tid; i < TT * S0 + K0; i += 256) xs[i] = load_norm(w, S0 * t0 + i, n, st.x, st.y);
     __syncthreads();
-    const int c = 2 * tid;
-    if (c >= C0) return;
-    float wa[K0], wb[K0];
+    const int ngrp = C0 / 8;                       // channel groups of 8
+    const int grp = tid % ngrp, tsub = tid / ngrp, tstep = 256 / ngrp;     // C0 = 512: 64 groups x 4 frame lanes
+    if (tsub >= tstep) return;
+    const int c = grp * 8;
+    float wr[8][K0], sc[8], sh[8];
 #pragma unroll
-    for (int k = 0; k < K0; ++k) { wa[k] = w0[c * K0 + k]; wb[k] = w0[(c + 1) * K0 + k]; }
-    float sa = 1.f, ha = 0.f, sb = 1.f, hb = 0.f;
-    if (mode == 0) {
-        float2 na = norm[(long)b * C0 + c], nb = norm[(long)b * C0 + c + 1];
-        sa = na.x; ha = na.y; sb = nb.x; hb = nb.y;
-    } else if (bias) {
-        ha = bias[c]; hb = bias[c + 1];
+    for (int j = 0; j < 8; ++j) {
+#pragma unroll
+        for (int k = 0; k < K0; ++k) wr[j][k] = w0[(c + j) * K0 + k];
+        sc[j] = 1.f; sh[j] = 0.f;
+        if (mode == 0) { float2 nn = norm[(long)b * C0 + c + j]; sc[j] = nn.x; sh[j] = nn.y; }
+        else if (bias) sh[j] = bias[c + j];
     }
     const int tend = min(TT, P0 - t0);
-    for (int t = 0; t < tend; ++t) {
-        float ya = 0.f, yb = 0.f;
+    for (int t = tsub; t < tend; t += tstep) {
+        f16x8 o = {0, 0, 0, 0, 0, 0, 0, 0};
         if (t0 + t < T0) {
+            float x[K0];
 #pragma unroll
-            for (int k = 0; k < K0; ++k) { float x = xs[S0 * t + k]; ya = fmaf(wa[k], x, ya); yb = fmaf(wb[k], x, yb); }
-            ya = ya * sa + ha; yb = yb * sb + hb;
-            if (mode == 0) {
-                ya = gelu_fast(ya);
-                yb = gelu_fast(yb);
+            for (int k = 0; k < K0; ++k) x[k] = xs[S0 * t + k];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float y = 0.f;
+#pragma unroll
+                for (int k = 0; k < K0; ++k) y = fmaf(wr[j][k], x[k], y);
+                y = y * sc[j] + sh[j];
+                if (mode == 0) y = gelu_fast(y);
+                o[j] = (_Float16)y;
             }
         }
-        __half2 h = __floats2half2_rn(ya, yb);
-        *(__half2*)(out + ((long)b * P0 + t0 + t) * C0 + c) = h;
+        *(f16x8*)(out + ((long)b * P0 + t0 + t) * C0 + c) = o;
     }
 }
 
@@ -165,7 +173,7 @@ using namespace advh;
 extern "C" int advh_w2v2_frontend(const float* wave, int64_t wave_stride, int n_in, int B, int L, const float* w0,
                                   const float* bias0, const float* gamma, const float* beta, int mode, int normalize, float* stats_ws,
                                   float* norm_ws, float* mr_ws, void* out, int T0, int P0, int C0, advh_stream_t stream) {
-    if (!wave || !w0 || !stats_ws || !out || B <= 0 || L < K0 || n_in <= 0 || C0 <= 0 || C0 > 512 || (C0 & 1)) return ADVH_EINVAL;
+    if (!wave || !w0 || !stats_ws || !out || B <= 0 || L < K0 || n_in <= 0 || C0 <= 0 || C0 > 2048 || (C0 % 8) || 256 % (C0 / 8 < 256 ? C0 / 8 : 256)) return ADVH_EINVAL;
     if (T0 != (L - K0) / S0 + 1 || P0 < T0 || wave_stride < (n_in < L ? n_in : L)) return ADVH_EINVAL;
     if (mode == 0 && (!gamma || !beta || !norm_ws)) return ADVH_EINVAL;
     if (mode != 0 && mode != 1) return ADVH_EINVAL;

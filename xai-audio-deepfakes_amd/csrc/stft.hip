@@ -10,6 +10,7 @@
 // LDS rows (fft512.h) where each of the 4 wavefronts runs whole 512-point transforms in place.
 #include <hip/hip_runtime.h>
 #include <mutex>
+#include <string.h>
 #include "addvisor_hip.h"
 #include "common.h"
 #include "fft512.h"
@@ -21,7 +22,9 @@ static bool g_init_done = false;
 
 constexpr int NFFT = 1024;
 constexpr int NBIN = 513;
-constexpr int FB = 16;           // frames per workgroup
+// frames per workgroup: template parameter FB (16: 64/128-byte runs per bin, 90 KB LDS = 1 workgroup per CU;
+// 8: half the run length, 45 KB = 3 workgroups per CU).  g_stft_fb selects it (advh_set_option).
+static int g_stft_fb = 8;
 constexpr int THREADS = 256;
 
 __device__ __forceinline__ void wave_fence() {
@@ -47,6 +50,7 @@ __device__ __forceinline__ void fft512_wave(float* re, float* im, int lane) {
 }
 
 // LDS carve: re rows | im rows | scratch (samples for the forward, overlap-add accumulator for the inverse)
+template <int FB>
 __device__ __forceinline__ void carve(float* smem, float*& re, float*& im, float*& scratch) {
     re = smem;
     im = smem + FB * FFT_ROW;
@@ -54,13 +58,14 @@ __device__ __forceinline__ void carve(float* smem, float*& re, float*& im, float
 }
 
 // ------------------------------------------------------------------------------------------ forward
+template <int FB>
 __global__ __launch_bounds__(THREADS) void stft_fwd_kernel(
     const float* __restrict__ wave, long wave_stride, int n_in, int L, int hop, int win,
     const float* __restrict__ window, float* __restrict__ X, float* __restrict__ mag,
     float* __restrict__ phase, int T) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *re, *im, *smp;
-    carve(smem, re, im, smp);
+    carve<FB>(smem, re, im, smp);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int b = blockIdx.y, tA = blockIdx.x * FB;
     const int left = (NFFT - win) / 2;
@@ -135,14 +140,14 @@ __global__ __launch_bounds__(THREADS) void stft_fwd_kernel(
 
 // ------------------------------------------------------------------------------------------ inverse
 // SRC 0: mag/phase (+ optional mask, mode), SRC 1: complex64 spectrogram
-template <int SRC>
+template <int SRC, int FB>
 __global__ __launch_bounds__(THREADS) void istft_kernel(
     const float* __restrict__ mag, const float* __restrict__ phase, const float* __restrict__ mask,
     int Fm, int Tm, int mode, int which0, float* __restrict__ out0, float* __restrict__ out1,
     long wave_stride, int T, int L, int hop, int win, int R, const float* __restrict__ window) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *re, *im, *acc;
-    carve(smem, re, im, acc);
+    carve<FB>(smem, re, im, acc);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int b = blockIdx.y, g = blockIdx.x;
     const int which = which0 + blockIdx.z;            // 0: mask-in, 1: mask-out
@@ -237,13 +242,23 @@ __global__ __launch_bounds__(THREADS) void istft_kernel(
     }
 }
 
-static size_t lds_bytes(int hop, int win) { return sizeof(float) * (2 * FB * FFT_ROW + (FB - 1) * hop + win); }
+static size_t lds_bytes(int FB, int hop, int win) { return sizeof(float) * (2 * FB * FFT_ROW + (FB - 1) * hop + win); }
 
 }  // namespace advh
 
 using namespace advh;
 
 extern "C" const char* advh_version(void) { return "addvisor_hip 0.1 (gfx950, wave64)"; }
+
+extern "C" int advh_set_option(const char* name, int value) {
+    if (!name) return ADVH_EINVAL;
+    if (!strcmp(name, "stft_frames_per_workgroup")) {
+        if (value != 8 && value != 16) return ADVH_EINVAL;
+        g_stft_fb = value;
+        return ADVH_OK;
+    }
+    return ADVH_EINVAL;
+}
 
 extern "C" int advh_init(void) {
     static std::mutex mu;
@@ -256,9 +271,10 @@ extern "C" int advh_init(void) {
     }
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_twiddle), host, sizeof(host)) != hipSuccess) return ADVH_ELAUNCH;
     const int maxlds = 160 * 1024;
-    if (hipFuncSetAttribute((const void*)stft_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, maxlds) != hipSuccess) return ADVH_ELAUNCH;
-    if (hipFuncSetAttribute((const void*)istft_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, maxlds) != hipSuccess) return ADVH_ELAUNCH;
-    if (hipFuncSetAttribute((const void*)istft_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, maxlds) != hipSuccess) return ADVH_ELAUNCH;
+    const void* big[] = {(const void*)stft_fwd_kernel<16>, (const void*)stft_fwd_kernel<8>, (const void*)istft_kernel<0, 16>,
+                         (const void*)istft_kernel<1, 16>, (const void*)istft_kernel<0, 8>, (const void*)istft_kernel<1, 8>};
+    for (const void* f : big)
+        if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, maxlds) != hipSuccess) return ADVH_ELAUNCH;
     int rc = advh_init_rest();
     if (rc != ADVH_OK) return rc;
     g_init_done = true;
@@ -269,7 +285,7 @@ static int check_frame_args(int B, int T, int L, int hop, int win) {
     if (!g_init_done) return ADVH_ENOTINIT;
     if (B <= 0 || L <= 0 || hop <= 0 || win <= 0 || win > NFFT || (win & 1) || T != 1 + L / hop) return ADVH_EINVAL;
     if (L <= NFFT / 2) return ADVH_EINVAL;           // reflect padding needs L > n_fft/2
-    if (lds_bytes(hop, win) > 160 * 1024) return ADVH_EUNSUPPORTED;
+    if (lds_bytes(g_stft_fb, hop, win) > 160 * 1024) return ADVH_EUNSUPPORTED;
     return ADVH_OK;
 }
 
@@ -279,9 +295,14 @@ extern "C" int advh_stft_forward(const float* wave, int64_t wave_stride, int n_i
     int rc = check_frame_args(B, T, L, hop, win);
     if (rc) return rc;
     if (!wave || n_in <= 0 || wave_stride < (n_in < L ? n_in : L)) return ADVH_EINVAL;
+    const int FB = g_stft_fb;
     dim3 grid((T + FB - 1) / FB, B);
-    hipLaunchKernelGGL(stft_fwd_kernel, grid, dim3(THREADS), lds_bytes(hop, win), (hipStream_t)stream, wave,
-                       (long)wave_stride, n_in, L, hop, win, window, X, mag, phase, T);
+    if (FB == 8)
+        hipLaunchKernelGGL(stft_fwd_kernel<8>, grid, dim3(THREADS), lds_bytes(8, hop, win), (hipStream_t)stream, wave,
+                           (long)wave_stride, n_in, L, hop, win, window, X, mag, phase, T);
+    else
+        hipLaunchKernelGGL(stft_fwd_kernel<16>, grid, dim3(THREADS), lds_bytes(16, hop, win), (hipStream_t)stream, wave,
+                           (long)wave_stride, n_in, L, hop, win, window, X, mag, phase, T);
     return hipGetLastError() == hipSuccess ? ADVH_OK : ADVH_ELAUNCH;
 }
 
@@ -291,6 +312,7 @@ static int launch_istft(int src, const float* a, const float* ph, const float* m
     int rc = check_frame_args(B, T, L, hop, win);
     if (rc) return rc;
     const int R = (win + hop - 1) / hop;
+    const int FB = g_stft_fb;
     if (R > FB / 2) return ADVH_EUNSUPPORTED;
     const int S = FB - R + 1, left = (NFFT - win) / 2;
     int which0 = 0, nz = 2;
@@ -300,12 +322,12 @@ static int launch_istft(int src, const float* a, const float* ph, const float* m
     else if (!o1) { nz = 1; }
     const int nG = (NFFT / 2 + L - left + S * hop - 1) / (S * hop);
     dim3 grid(nG, B, nz);
-    if (src == 0)
-        hipLaunchKernelGGL(istft_kernel<0>, grid, dim3(THREADS), lds_bytes(hop, win), (hipStream_t)stream, a, ph, mask,
-                           Fm, Tm, mode, which0, p0, p1, (long)ws, T, L, hop, win, R, window);
-    else
-        hipLaunchKernelGGL(istft_kernel<1>, grid, dim3(THREADS), lds_bytes(hop, win), (hipStream_t)stream, a, ph, mask,
-                           Fm, Tm, mode, which0, p0, p1, (long)ws, T, L, hop, win, R, window);
+#define ISTFT_LAUNCH(SRC_, FB_)                                                                                          \
+    hipLaunchKernelGGL((istft_kernel<SRC_, FB_>), grid, dim3(THREADS), lds_bytes(FB_, hop, win), (hipStream_t)stream, a, ph,  \
+                       mask, Fm, Tm, mode, which0, p0, p1, (long)ws, T, L, hop, win, R, window)
+    if (src == 0) { if (FB == 8) ISTFT_LAUNCH(0, 8); else ISTFT_LAUNCH(0, 16); }
+    else { if (FB == 8) ISTFT_LAUNCH(1, 8); else ISTFT_LAUNCH(1, 16); }
+#undef ISTFT_LAUNCH
     return hipGetLastError() == hipSuccess ? ADVH_OK : ADVH_ELAUNCH;
 }
 
