@@ -44,8 +44,10 @@ def main():
     ap.add_argument("--rehearse", action="store_true",
                     help="multi-rank dry run on ONE GPU: gloo backend, every rank on cuda:0 (checks the sharding / "
                          "gather / timing logic where no multi-GPU node is available; not a measurement)")
-    ap.add_argument("--no-tune", action="store_true", help="keep the default 128x128 GEMM tile everywhere")
-    ap.add_argument("--cpu-clips", type=int, default=4)
+    ap.add_argument("--tune", action="store_true",
+                    help="time every candidate GEMM tile per launch first and keep the fastest (default: the 128x128 tile)")
+    ap.add_argument("--no-tune", action="store_true", help=argparse.SUPPRESS)       # kept for old command lines
+    ap.add_argument("--cpu-clips", type=int, default=32)
     ap.add_argument("--cpu-threads", type=int, default=16, help="host threads for the CPU baseline (a 1-GPU box owns 16)")
     args = ap.parse_args()
 
@@ -84,7 +86,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if not args.no_tune:
+    if args.tune:
         pipe.tune(B)                                   # per-launch GEMM tile selection, outside the timed region
         if args.verbose and rank == 0:
             for rec in G.TUNER.log:
@@ -123,6 +125,13 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(cfg, emb_sd, coef, icpt, unet_sd, args.cpu_clips, L, args.cpu_threads)
 
+    traffic = None                       # HBM bytes per launch of the dominant kernel, from the committed PMC passes
+    tpath = os.path.join(ROOT, "profiles", "r01_gemm_traffic.json")
+    if os.path.exists(tpath) and not args.tune:
+        with open(tpath) as fh:
+            for k, v in json.load(fh).items():
+                if "gemm_f16_kernel<128, 128" in k:
+                    traffic = round(v["hbm_bytes_per_launch"])
     if rank == 0:
         line = {
             "metric": "explanations/sec (16 kHz, 4 s clips)", "value": round(value, 2), "unit": "explanations/s",
@@ -137,10 +146,11 @@ def main():
                        "gflop_per_explanation": round(flops_step / B / 1e9, 1)},
             "lmac": {k: round(v, 6) for k, v in metrics.items()},
             "pipeline_tflops": round(flops_step * args.steps * world / elapsed / 1e12, 1),
-            "roofline": {"kernel": "gemm_f16 (128x128 / pipelined 256x256 / 256x128 tiles, csrc/gemm.hip)", "bound": "mfma",
+            "roofline": {"kernel": "gemm_f16_kernel<128,128,2,2>" + (" (+ tuned 256-wide tiles)" if args.tune else ""), "bound": "mfma",
                          "achieved": None if achieved is None else round(achieved, 1), "peak": MFMA_F16_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": None if achieved is None else round(achieved / MFMA_F16_PEAK_TFLOPS, 4),
-                         "traffic": None, "launches": gemm_n,
+                         "traffic": traffic, "traffic_source": "profiles/r01_gemm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
+                         "FETCH_SIZE x2 per MI355X_MICROARCH.md; bytes per launch)" if traffic else None, "launches": gemm_n,
                          "avg_launch_us": None if not gemm_n else round(1e3 * gemm_ms / gemm_n, 2),
                          "gflop_per_launch": None if not gemm_n else round(gemm_flops / gemm_n / 1e9, 2)},
             "cpu_baseline": cpu,
