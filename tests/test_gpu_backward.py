@@ -41,7 +41,7 @@ def test_layernorm_bwd(gpu_device):
         assert relerr(out.cpu(), ref + add) < 2e-5
 
 
-@pytest.mark.parametrize("T,heads,D", [(199, 3, 64), (50, 2, 32), (249, 2, 64)])
+@pytest.mark.parametrize("T,heads,D", [(199, 3, 64), (50, 2, 32), (249, 2, 64), (199, 2, 120), (60, 1, 40)])
 def test_attention_bwd(gpu_device, T, heads, D):
     _lib.init()
     g = torch.Generator().manual_seed(T)

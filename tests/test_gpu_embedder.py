@@ -78,3 +78,11 @@ def test_batch_invariance(gpu_device):
     h5, l5, _ = emb.forward(w)
     h2, l2, _ = emb.forward(w[1:3].contiguous())
     assert torch.equal(h5[1:3], h2) and torch.equal(l5[1:3], l2)
+
+
+def test_xlsr_shaped_embedder(gpu_device):
+    """The reference's own embedder family (XLS-R-2B: hidden 1920, 16 heads -> head_dim 120, layer-norm feature
+    extractor, pre-LN encoder) at reduced width/depth: hidden 240 / 2 heads keeps head_dim = 120."""
+    cfg = syn.tiny_config(True, hidden_size=240, num_attention_heads=2, intermediate_size=480,
+                          num_conv_pos_embedding_groups=2, num_hidden_layers=10)
+    run_case(cfg, syn.make_clips(2, 16000, seed=33), gpu_device)

@@ -46,8 +46,8 @@ class HipEmbedder:
         self.sd = {k: v.detach().float() for k, v in sd.items()}
         if cfg.conv_kernel[0] != 10 or cfg.conv_stride[0] != 5:
             raise ValueError("feature-encoder layer 0 must be Conv1d(k=10, stride=5)")
-        if cfg.head_dim not in (32, 64):
-            raise ValueError("attention kernel supports head_dim 32 / 64")
+        if cfg.head_dim % 8 or cfg.head_dim > 128:
+            raise ValueError("attention kernel supports head dims that are multiples of 8 up to 128")
         self.nl = min(cfg.layer_index, cfg.num_hidden_layers)
         dev = device
         p0 = "feature_extractor.conv_layers.0."

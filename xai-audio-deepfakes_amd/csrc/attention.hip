@@ -19,28 +19,31 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// D = head dim rounded up to a multiple of 32 (MFMA k step); dm = the real head dim (a multiple of 8): chunks beyond
+// it are zero-filled on load and skipped on store (XLS-R-2B: 1920 / 16 heads = 120 -> D = 128).
 template <int NT, int D>
 __global__ __launch_bounds__(256) void attention_kernel(const _Float16* __restrict__ qkv, _Float16* __restrict__ ctx,
-                                                        int T, int H, float scale) {
+                                                        int T, int H, int dm, float scale) {
     constexpr int NKEY = NT * 16, CH = D / 8, VP = NKEY + 64 /* row pitch incl. the per-8-rows skew that spreads the transposing stores over the banks */, NS = (NT + 1) / 2, KK = D / 32, DT = D / 16;
     __shared__ __attribute__((aligned(16))) _Float16 Ks[NKEY * D];
     __shared__ __attribute__((aligned(16))) _Float16 Vt[D * VP];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int head = blockIdx.x, b = blockIdx.y;
     const long ld = 3L * H;
-    const _Float16* base = qkv + (long)b * T * ld + head * D;
+    const _Float16* base = qkv + (long)b * T * ld + head * dm;
+    const int chm = dm / 8;                          // real 16-byte chunks per row
 
     // ---- stage K (row-major, 16-byte chunks XOR-swizzled by row) and V^T; keys >= T are zero
     for (int i = tid; i < NKEY * CH; i += 256) {
         int key = i / CH, c = i % CH;
         f16x8 kv = {0, 0, 0, 0, 0, 0, 0, 0}, vv = kv;
-        if (key < T) {
+        if (key < T && c < chm) {
             kv = *(const f16x8*)(base + (long)key * ld + H + c * 8);
             vv = *(const f16x8*)(base + (long)key * ld + 2 * H + c * 8);
         }
         *(f16x8*)(Ks + key * D + ((c ^ (key & (CH - 1))) * 8)) = kv;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) Vt[(c * 8 + j) * VP + c * 8 + key] = vv[j];
+        for (int j = 0; j < 8; ++j) Vt[(c * 8 + j) * VP + (c & 7) * 8 + key] = vv[j];
     }
     __syncthreads();
 
@@ -50,7 +53,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const _Float16* __restri
         int qr = qrow < T ? qrow : T - 1;
         f16x8 qf[KK];
 #pragma unroll
-        for (int kk = 0; kk < KK; ++kk) qf[kk] = *(const f16x8*)(base + (long)qr * ld + kk * 32 + g * 8);
+        for (int kk = 0; kk < KK; ++kk)
+            qf[kk] = (kk * 4 + g < chm) ? *(const f16x8*)(base + (long)qr * ld + kk * 32 + g * 8) : f16x8{0, 0, 0, 0, 0, 0, 0, 0};
 
         // S^T tiles: rows = keys (4g + r within the tile), column = this lane's query
         f32x4 s[NT];
@@ -102,7 +106,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const _Float16* __restri
         for (int ss = 0; ss < NS; ++ss) {
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
-                const _Float16* vr = Vt + (dt * 16 + fr) * VP + ((dt * 16 + fr) >> 3) * 8 + ss * 32 + g * 4;
+                const _Float16* vr = Vt + (dt * 16 + fr) * VP + (((dt * 16 + fr) >> 3) & 7) * 8 + ss * 32 + g * 4;
                 f16x4 lo = *(const f16x4*)vr;
                 f16x4 hi = (2 * ss + 1 < NT) ? *(const f16x4*)(vr + 16) : f16x4{0, 0, 0, 0};
                 f16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -112,8 +116,9 @@ __global__ __launch_bounds__(256) void attention_kernel(const _Float16* __restri
         if (qrow < T) {
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
+                if (dt * 16 + g * 4 >= dm) continue;
                 f16x4 hv = {(_Float16)o[dt][0], (_Float16)o[dt][1], (_Float16)o[dt][2], (_Float16)o[dt][3]};
-                *(f16x4*)(ctx + ((long)b * T + qrow) * H + head * D + dt * 16 + g * 4) = hv;
+                *(f16x4*)(ctx + ((long)b * T + qrow) * H + head * dm + dt * 16 + g * 4) = hv;
             }
         }
     }
@@ -125,17 +130,20 @@ using namespace advh;
 
 extern "C" int advh_attention_f16(const void* qkv, void* ctx, int B, int T, int H, int heads, advh_stream_t stream) {
     if (!qkv || !ctx || B <= 0 || T <= 0 || heads <= 0 || H % heads) return ADVH_EINVAL;
-    const int D = H / heads;
-    if (T > 256 || (D != 64 && D != 32)) return ADVH_EUNSUPPORTED;
-    const float scale = 1.f / sqrtf((float)D);
+    const int dm = H / heads;
+    if (T > 256 || dm % 8 || dm > 128) return ADVH_EUNSUPPORTED;
+    const int D = dm <= 32 ? 32 : (dm <= 64 ? 64 : 128);
+    const float scale = 1.f / sqrtf((float)dm);
     dim3 grid(heads, B), block(256);
     hipStream_t s = (hipStream_t)stream;
     const int nt = (T + 15) / 16;
-#define ATT(NT_, D_) hipLaunchKernelGGL((attention_kernel<NT_, D_>), grid, block, 0, s, (const _Float16*)qkv, (_Float16*)ctx, T, H, scale)
+#define ATT(NT_, D_) hipLaunchKernelGGL((attention_kernel<NT_, D_>), grid, block, 0, s, (const _Float16*)qkv, (_Float16*)ctx, T, H, dm, scale)
     if (D == 64) {
         if (nt <= 4) ATT(4, 64); else if (nt <= 8) ATT(8, 64); else if (nt <= 13) ATT(13, 64); else ATT(16, 64);
-    } else {
+    } else if (D == 32) {
         if (nt <= 4) ATT(4, 32); else if (nt <= 8) ATT(8, 32); else if (nt <= 13) ATT(13, 32); else ATT(16, 32);
+    } else {
+        if (nt <= 4) ATT(4, 128); else if (nt <= 13) ATT(13, 128); else ATT(16, 128);
     }
 #undef ATT
     return ADVH_LAUNCH_CHECK();

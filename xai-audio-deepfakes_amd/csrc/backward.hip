@@ -134,40 +134,45 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
 // Recomputing S and dP in both orientations costs 2x of a small op and needs no transposes or atomics.
 template <int NT, int D>
 __global__ __launch_bounds__(256) void attention_bwd_kernel(const _Float16* __restrict__ qkv, const _Float16* __restrict__ dctx,
-                                                            _Float16* __restrict__ dqkv, int T, int H, float scale) {
+                                                            _Float16* __restrict__ dqkv, int T, int H, int dm, float scale) {
     constexpr int NKEY = NT * 16, CH = D / 8, VP = NKEY + 64, NS = (NT + 1) / 2, KK = D / 32, DT = D / 16;
     constexpr int ROWB = NKEY * D, TRB = D * VP;
     // LDS: pass A uses K | V (row-major, swizzled) | Kt ; pass B re-uses the space for Qt | dOt ; stats stay.
+    // For D = 128 V is not staged (pass A reads its fragments from global memory) to stay inside 160 KiB.
+    constexpr bool STAGE_V = D <= 64;
+    constexpr int LDSH = (STAGE_V ? 2 * ROWB + TRB : ROWB + TRB) > 2 * TRB ? (STAGE_V ? 2 * ROWB + TRB : ROWB + TRB) : 2 * TRB;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     _Float16* Ks = (_Float16*)smem_raw;
     _Float16* Vs = Ks + ROWB;
-    _Float16* Kt = Vs + ROWB;
+    _Float16* Kt = STAGE_V ? Vs + ROWB : Vs;
     _Float16* Qt = (_Float16*)smem_raw;
     _Float16* dOt = Qt + TRB;
-    float* rmax = (float*)(smem_raw + (2 * ROWB + TRB) * 2);
+    float* rmax = (float*)(smem_raw + LDSH * 2);
     float* rinv = rmax + NKEY;
     float* rdel = rinv + NKEY;
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int head = blockIdx.x, b = blockIdx.y;
     const long ld = 3L * H;
-    const _Float16* base = qkv + (long)b * T * ld + head * D;      // q at +0, k at +H, v at +2H
-    const _Float16* dob = dctx + (long)b * T * H + head * D;
-    _Float16* dbase = dqkv + (long)b * T * ld + head * D;
+    const _Float16* base = qkv + (long)b * T * ld + head * dm;     // q at +0, k at +H, v at +2H
+    const _Float16* dob = dctx + (long)b * T * H + head * dm;
+    _Float16* dbase = dqkv + (long)b * T * ld + head * dm;
+    const int chm = dm / 8;                                        // real 16-byte chunks per row (D - dm is zero padding)
+    const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
     const int fr = lane & 15, g = lane >> 4;
 
     for (int i = tid; i < NKEY * CH; i += 256) {
         int key = i / CH, c = i % CH;
         f16x8 kv = {0, 0, 0, 0, 0, 0, 0, 0}, vv = kv;
-        if (key < T) {
+        if (key < T && c < chm) {
             kv = *(const f16x8*)(base + (long)key * ld + H + c * 8);
             vv = *(const f16x8*)(base + (long)key * ld + 2 * H + c * 8);
         }
         int sw = ((c ^ (key & (CH - 1))) * 8);
         *(f16x8*)(Ks + key * D + sw) = kv;
-        *(f16x8*)(Vs + key * D + sw) = vv;
+        if (STAGE_V) *(f16x8*)(Vs + key * D + sw) = vv;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) Kt[(c * 8 + j) * VP + c * 8 + key] = kv[j];
+        for (int j = 0; j < 8; ++j) Kt[(c * 8 + j) * VP + (c & 7) * 8 + key] = kv[j];
     }
     __syncthreads();
 
@@ -178,8 +183,8 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const _Float16* __re
         f16x8 qf[KK], of[KK];
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) {
-            qf[kk] = *(const f16x8*)(base + (long)qr * ld + kk * 32 + g * 8);
-            of[kk] = *(const f16x8*)(dob + (long)qr * H + kk * 32 + g * 8);
+            qf[kk] = (kk * 4 + g < chm) ? *(const f16x8*)(base + (long)qr * ld + kk * 32 + g * 8) : zero8;
+            of[kk] = (kk * 4 + g < chm) ? *(const f16x8*)(dob + (long)qr * H + kk * 32 + g * 8) : zero8;
         }
         f32x4 s[NT], dp[NT];
 #pragma unroll
@@ -191,7 +196,9 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const _Float16* __re
                 int key = kt * 16 + fr, c = kk * 4 + g;
                 int sw = ((c ^ (key & (CH - 1))) * 8);
                 f16x8 kf = *(const f16x8*)(Ks + key * D + sw);
-                f16x8 vf = *(const f16x8*)(Vs + key * D + sw);
+                f16x8 vf;
+                if (STAGE_V) vf = *(const f16x8*)(Vs + key * D + sw);
+                else vf = (key < T && c < chm) ? *(const f16x8*)(base + (long)key * ld + 2 * H + c * 8) : zero8;
                 s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[kk], s[kt], 0, 0, 0);      // S^T  [key][q]
                 dp[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, of[kk], dp[kt], 0, 0, 0);    // dP^T [key][q]
             }
@@ -241,7 +248,7 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const _Float16* __re
         for (int ss = 0; ss < NS; ++ss) {
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
-                const _Float16* kr = Kt + (dt * 16 + fr) * VP + ((dt * 16 + fr) >> 3) * 8 + ss * 32 + g * 4;
+                const _Float16* kr = Kt + (dt * 16 + fr) * VP + (((dt * 16 + fr) >> 3) & 7) * 8 + ss * 32 + g * 4;
                 f16x4 lo = *(const f16x4*)kr;
                 f16x4 hi = (2 * ss + 1 < NT) ? *(const f16x4*)(kr + 16) : f16x4{0, 0, 0, 0};
                 f16x8 kf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -251,6 +258,7 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const _Float16* __re
         if (qrow < T) {
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
+                if (dt * 16 + g * 4 >= dm) continue;
                 f16x4 hv = {(_Float16)o[dt][0], (_Float16)o[dt][1], (_Float16)o[dt][2], (_Float16)o[dt][3]};
                 *(f16x4*)(dbase + (long)qrow * ld + dt * 16 + g * 4) = hv;
             }
@@ -262,12 +270,12 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const _Float16* __re
     for (int i = tid; i < NKEY * CH; i += 256) {
         int row = i / CH, c = i % CH;
         f16x8 qv = {0, 0, 0, 0, 0, 0, 0, 0}, ov = qv;
-        if (row < T) {
+        if (row < T && c < chm) {
             qv = *(const f16x8*)(base + (long)row * ld + c * 8);
             ov = *(const f16x8*)(dob + (long)row * H + c * 8);
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { Qt[(c * 8 + j) * VP + c * 8 + row] = qv[j]; dOt[(c * 8 + j) * VP + c * 8 + row] = ov[j]; }
+        for (int j = 0; j < 8; ++j) { Qt[(c * 8 + j) * VP + (c & 7) * 8 + row] = qv[j]; dOt[(c * 8 + j) * VP + (c & 7) * 8 + row] = ov[j]; }
     }
     __syncthreads();
     for (int kt = wv; kt * 16 < T; kt += 4) {
@@ -276,8 +284,8 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const _Float16* __re
         f16x8 kf[KK], vf[KK];
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) {
-            kf[kk] = *(const f16x8*)(base + (long)kr * ld + H + kk * 32 + g * 8);
-            vf[kk] = *(const f16x8*)(base + (long)kr * ld + 2 * H + kk * 32 + g * 8);
+            kf[kk] = (kk * 4 + g < chm) ? *(const f16x8*)(base + (long)kr * ld + H + kk * 32 + g * 8) : zero8;
+            vf[kk] = (kk * 4 + g < chm) ? *(const f16x8*)(base + (long)kr * ld + 2 * H + kk * 32 + g * 8) : zero8;
         }
         f32x4 dvt[DT], dkt[DT];
 #pragma unroll
@@ -294,8 +302,8 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const _Float16* __re
                 if (qt < NT) {
 #pragma unroll
                     for (int kk = 0; kk < KK; ++kk) {
-                        f16x8 qf = *(const f16x8*)(base + (long)qr * ld + kk * 32 + g * 8);
-                        f16x8 of = *(const f16x8*)(dob + (long)qr * H + kk * 32 + g * 8);
+                        f16x8 qf = (kk * 4 + g < chm) ? *(const f16x8*)(base + (long)qr * ld + kk * 32 + g * 8) : zero8;
+                        f16x8 of = (kk * 4 + g < chm) ? *(const f16x8*)(dob + (long)qr * H + kk * 32 + g * 8) : zero8;
                         s = __builtin_amdgcn_mfma_f32_16x16x32_f16(qf, kf[kk], s, 0, 0, 0);      // S  [q][key]
                         dp = __builtin_amdgcn_mfma_f32_16x16x32_f16(of, vf[kk], dp, 0, 0, 0);    // dP [q][key]
                     }
@@ -314,8 +322,8 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const _Float16* __re
             }
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
-                const _Float16* orow = dOt + (dt * 16 + fr) * VP + ((dt * 16 + fr) >> 3) * 8 + ss * 32 + g * 4;
-                const _Float16* qrow_ = Qt + (dt * 16 + fr) * VP + ((dt * 16 + fr) >> 3) * 8 + ss * 32 + g * 4;
+                const _Float16* orow = dOt + (dt * 16 + fr) * VP + (((dt * 16 + fr) >> 3) & 7) * 8 + ss * 32 + g * 4;
+                const _Float16* qrow_ = Qt + (dt * 16 + fr) * VP + (((dt * 16 + fr) >> 3) & 7) * 8 + ss * 32 + g * 4;
                 f16x4 olo = *(const f16x4*)orow, qlo = *(const f16x4*)qrow_;
                 f16x4 ohi = (2 * ss + 1 < NT) ? *(const f16x4*)(orow + 16) : f16x4{0, 0, 0, 0};
                 f16x4 qhi = (2 * ss + 1 < NT) ? *(const f16x4*)(qrow_ + 16) : f16x4{0, 0, 0, 0};
@@ -328,6 +336,7 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const _Float16* __re
         if (krow < T) {
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
+                if (dt * 16 + g * 4 >= dm) continue;
                 f16x4 kv = {(_Float16)dkt[dt][0], (_Float16)dkt[dt][1], (_Float16)dkt[dt][2], (_Float16)dkt[dt][3]};
                 f16x4 vv = {(_Float16)dvt[dt][0], (_Float16)dvt[dt][1], (_Float16)dvt[dt][2], (_Float16)dvt[dt][3]};
                 *(f16x4*)(dbase + (long)krow * ld + H + dt * 16 + g * 4) = kv;
@@ -447,9 +456,11 @@ extern "C" int advh_layernorm_bwd(const void* x, int x_is_f32, const void* dy, i
 }
 
 template <int NT, int D>
-static int launch_att_bwd(const void* qkv, const void* dctx, void* dqkv, int B, int T, int H, int heads, float scale, hipStream_t s) {
-    constexpr int NKEY = NT * 16, VP = NKEY + 64;
-    const size_t lds = (size_t)(2 * NKEY * D + D * VP) * 2 + 3 * NKEY * 4;
+static int launch_att_bwd(const void* qkv, const void* dctx, void* dqkv, int B, int T, int H, int heads, int dm, float scale, hipStream_t s) {
+    constexpr int NKEY = NT * 16, VP = NKEY + 64, ROWB = NKEY * D, TRB = D * VP;
+    constexpr int PA = D <= 64 ? 2 * ROWB + TRB : ROWB + TRB;
+    const size_t lds = (size_t)(PA > 2 * TRB ? PA : 2 * TRB) * 2 + 3 * NKEY * 4;
+    if (lds > 160 * 1024) return ADVH_EUNSUPPORTED;
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute((const void*)attention_bwd_kernel<NT, D>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
@@ -457,21 +468,23 @@ static int launch_att_bwd(const void* qkv, const void* dctx, void* dqkv, int B, 
         attr_done = true;
     }
     hipLaunchKernelGGL((attention_bwd_kernel<NT, D>), dim3(heads, B), dim3(256), lds, s, (const _Float16*)qkv, (const _Float16*)dctx,
-                       (_Float16*)dqkv, T, H, scale);
+                       (_Float16*)dqkv, T, H, dm, scale);
     return ADVH_LAUNCH_CHECK();
 }
 
 extern "C" int advh_attention_bwd_f16(const void* qkv, const void* dctx, void* dqkv, int B, int T, int H, int heads,
                                       advh_stream_t stream) {
     if (!qkv || !dctx || !dqkv || B <= 0 || T <= 0 || heads <= 0 || H % heads) return ADVH_EINVAL;
-    const int D = H / heads;
-    if (T > 256 || (D != 64 && D != 32)) return ADVH_EUNSUPPORTED;
-    const float scale = 1.f / sqrtf((float)D);
+    const int dm = H / heads;
+    if (T > 256 || dm % 8 || dm > 128) return ADVH_EUNSUPPORTED;
+    const int D = dm <= 32 ? 32 : (dm <= 64 ? 64 : 128);
+    const float scale = 1.f / sqrtf((float)dm);
     hipStream_t s = (hipStream_t)stream;
     const int nt = (T + 15) / 16;
-#define ATB(NT_, D_) return launch_att_bwd<NT_, D_>(qkv, dctx, dqkv, B, T, H, heads, scale, s)
+#define ATB(NT_, D_) return launch_att_bwd<NT_, D_>(qkv, dctx, dqkv, B, T, H, heads, dm, scale, s)
     if (D == 64) { if (nt <= 4) ATB(4, 64); else if (nt <= 8) ATB(8, 64); else if (nt <= 13) ATB(13, 64); else ATB(16, 64); }
-    else { if (nt <= 4) ATB(4, 32); else if (nt <= 8) ATB(8, 32); else if (nt <= 13) ATB(13, 32); else ATB(16, 32); }
+    else if (D == 32) { if (nt <= 4) ATB(4, 32); else if (nt <= 8) ATB(8, 32); else if (nt <= 13) ATB(13, 32); else ATB(16, 32); }
+    else { if (nt <= 4) ATB(4, 128); else if (nt <= 13) ATB(13, 128); else ATB(16, 128); }
 #undef ATB
 }
 
