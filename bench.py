@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--streams", type=int, default=1, help="HIP streams the 3B embedder batch is split over")
     ap.add_argument("--rehearse", action="store_true",
                     help="multi-rank dry run on ONE GPU: gloo backend, every rank on cuda:0 (checks the sharding / "
                          "gather / timing logic where no multi-GPU node is available; not a measurement)")
@@ -74,7 +75,7 @@ def main():
     emb_sd = syn.embedder_weights(cfg)
     coef, icpt = syn.logreg_weights(cfg.hidden_size)
     unet_sd = syn.unet_weights()
-    pipe = P.ExplainPipeline(cfg, emb_sd, coef, icpt, unet_sd, dev, audio_length=AUDIO_LENGTH)
+    pipe = P.ExplainPipeline(cfg, emb_sd, coef, icpt, unet_sd, dev, audio_length=AUDIO_LENGTH, streams=args.streams)
 
     B, L = args.batch, AUDIO_LENGTH * 16000
     n_batches = max(1, min(args.steps, 8))

@@ -66,7 +66,7 @@ class HipEmbedder:
         self.intercept = float(np.asarray(intercept).reshape(-1)[0])
         if self.coef.numel() != cfg.hidden_size:
             raise ValueError("logreg coef_ must have hidden_size entries")
-        self._ws: Dict[Tuple[int, int], dict] = {}
+        self._ws: Dict[Tuple[int, int, int], dict] = {}
 
     # ------------------------------------------------------------------ planning (once per batch shape)
     def _lengths(self, L: int) -> List[int]:
@@ -76,8 +76,8 @@ class HipEmbedder:
             out.append(n)
         return out
 
-    def _workspace(self, B: int, L: int) -> dict:
-        key = (B, L)
+    def _workspace(self, B: int, L: int, slot: int = 0) -> dict:
+        key = (B, L, slot)
         if key in self._ws:
             return self._ws[key]
         cfg, dev, sd = self.cfg, self.dev, self.sd
@@ -163,7 +163,7 @@ class HipEmbedder:
 
     # ------------------------------------------------------------------ forward
     def forward(self, wave: torch.Tensor, length: Optional[int] = None, want_hidden: bool = True,
-                normalize: bool = True):
+                normalize: bool = True, slot: int = 0):
         """Returns ``(hidden [B,T,H] fp32 or None, logits [B,1], probs [B,1])`` -- fresh tensors."""
         if wave.dim() != 2 or wave.dtype != torch.float32 or not wave.is_cuda:
             raise ValueError("wave must be a CUDA fp32 tensor [B, n]")
@@ -171,7 +171,7 @@ class HipEmbedder:
         B, n_in = wave.shape
         L = n_in if length is None else int(length)
         cfg, lib = self.cfg, _lib.lib()
-        ws = self._workspace(B, L)
+        ws = self._workspace(B, L, slot)           # `slot` gives concurrent streams their own buffers
         st = torch.cuda.current_stream().cuda_stream
         Ls, P, T, M, H = ws["Ls"], ws["P"], ws["T"], ws["M"], cfg.hidden_size
         eps = cfg.layer_norm_eps

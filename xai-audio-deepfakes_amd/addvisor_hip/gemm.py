@@ -18,10 +18,10 @@ from . import _lib
 
 BK = 64
 ACT = {"none": 0, "gelu": 1, "leaky": 2}
-TILE_AUTO, TILE_128x128, TILE_256x64, TILE_256x32, TILE_256x256, TILE_256x128, TILE_256x128_W4, TILE_128x256_W4 = 0, 1, 2, 3, 4, 5, 6, 7
-TILE_BN = {TILE_128x128: 128, TILE_256x64: 64, TILE_256x32: 32, TILE_256x256: 256, TILE_256x128: 128, TILE_256x128_W4: 128, TILE_128x256_W4: 256}
+TILE_AUTO, TILE_128x128, TILE_256x64, TILE_256x32, TILE_256x256, TILE_256x128, TILE_256x128_W4, TILE_128x256_W4, TILE_256x256_RING = 0, 1, 2, 3, 4, 5, 6, 7, 8
+TILE_BN = {TILE_128x128: 128, TILE_256x64: 64, TILE_256x32: 32, TILE_256x256: 256, TILE_256x128: 128, TILE_256x128_W4: 128, TILE_128x256_W4: 256, TILE_256x256_RING: 256}
 TILE_NAMES = {TILE_128x128: "128x128", TILE_256x64: "256x64", TILE_256x32: "256x32", TILE_256x256: "256x256p", TILE_256x128: "256x128p",
-              TILE_256x128_W4: "256x128w4", TILE_128x256_W4: "128x256w4"}
+              TILE_256x128_W4: "256x128w4", TILE_128x256_W4: "128x256w4", TILE_256x256_RING: "256x256r"}
 
 
 class GemmDesc(C.Structure):

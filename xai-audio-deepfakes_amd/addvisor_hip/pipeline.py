@@ -26,12 +26,16 @@ METRIC_NAMES = ("faithfulness", "fidelity", "AD", "AI", "AG")
 class ExplainPipeline:
     def __init__(self, emb_cfg: EmbedderConfig, emb_sd, coef, intercept, unet_sd, device,
                  audio_length: float = 4, sampling_rate: int = 16000, domain: str = "log1p",
-                 hop: int = 322, win: int = 644):
+                 hop: int = 322, win: int = 644, streams: int = 1):
         self.dev = device
         self.L = int(audio_length * sampling_rate)
         self.hop, self.win, self.domain = hop, win, domain
         self.embedder = HipEmbedder(emb_cfg, emb_sd, coef, intercept, device)
         self.unet = HipUNet(unet_sd, device)
+        # the 3B embedder batch can be split over several HIP streams: kernels of independent sub-batches then
+        # fill each other's tail waves and launch gaps (utterances are independent)
+        self.nstreams = max(1, streams)
+        self._streams = [torch.cuda.Stream(device=device) for _ in range(self.nstreams - 1)]
 
     def explain(self, waves: torch.Tensor, keep: bool = False) -> Dict[str, torch.Tensor]:
         """``waves [B, n]`` fp32 on the GPU -> clean / mask-in / mask-out probabilities ``[B,1]`` and the mask."""
@@ -51,7 +55,19 @@ class ExplainPipeline:
             {"linear": 1, "log1p": 2}[self.domain], allw[B:].data_ptr(), allw[2 * B:].data_ptr(), L, B, mag.shape[2], L,
             self.hop, self.win, None, torch.cuda.current_stream().cuda_stream)
         _lib.check(rc, "advh_istft_masked")
-        _, _, p3 = self.embedder.forward(allw, L, want_hidden=False)
+        if self.nstreams == 1 or (3 * B) % self.nstreams:
+            _, _, p3 = self.embedder.forward(allw, L, want_hidden=False)
+        else:
+            cur = torch.cuda.current_stream()
+            per = 3 * B // self.nstreams
+            parts = [None] * self.nstreams
+            for i, st in enumerate([cur] + self._streams):
+                st.wait_stream(cur)
+                with torch.cuda.stream(st):
+                    parts[i] = self.embedder.forward(allw[i * per:(i + 1) * per], L, want_hidden=False, slot=i)[2]
+            for st in self._streams:
+                cur.wait_stream(st)
+            p3 = torch.cat(parts, 0)
         p_clean, p2, both = p3[:B], p3[B:], allw[B:]
         out = dict(predictions=p_clean, theta_out=p2[:B], masked_predictions=p2[B:], mask=mask)
         if keep:

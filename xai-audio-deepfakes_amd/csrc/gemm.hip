@@ -405,6 +405,140 @@ static int launch_pipe(const advh_gemm_desc& d, hipStream_t s) {
     return ADVH_LAUNCH_CHECK();
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Ring variant: 512 threads, BM x BN x 32 K-tiles in a 4-stage LDS ring (32 KiB per stage at 256 x 256).
+// Three K-tiles are in flight at any time and the DMA stream is continuous: the wait at the top of an
+// iteration only retires the OLDEST tile (counted vmcnt), the two younger ones keep flying across the barrier.
+// 64-byte LDS rows (4 chunks): chunk c of row r lives at slot c ^ ((r >> 1) & 2), which is conflict-free for
+// the ds_read_b128 lane groups (checked by enumeration in tests/test_gemm_plan.py).
+constexpr int RK = 32, RSTAGES = 4, RING_KTAB_MAX = 2048;
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(512) void gemm_f16_ring_kernel(const advh_gemm_desc p) {
+    constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 16, NI = TN / 16;
+    constexpr int NA = BM / 128, NB = BN / 128;    // 16-byte chunks per thread per K-tile (512 threads, 4 chunks / row)
+    constexpr int STAGE = (BM + BN) * RK * 2;
+    constexpr int NLOAD = NA + NB;
+    static_assert(WM * WN == 8 && MI % 2 == 0, "8 wavefronts");
+    extern __shared__ __attribute__((aligned(16))) char dsmem[];
+    int* kt_lds = (int*)(dsmem + RSTAGES * STAGE);
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wm = wv / WN, wn = wv % WN;
+    const int tilesN = (p.N + BN - 1) / BN;
+    const int nwg = gridDim.x;
+    int id = blockIdx.x;
+    {
+        const int q8 = nwg / 8, r8 = nwg % 8, xcd = id % 8;
+        id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + id / 8;
+    }
+    const int tile_n = id % tilesN, tile_m = id / tilesN;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int z = blockIdx.z;
+    const _Float16* A0 = (const _Float16*)p.A0 + p.a_sZ[0] * z * 8;
+    const _Float16* A1 = (const _Float16*)p.A1 + p.a_sZ[1] * z * 8;
+    const _Float16* Wp = (const _Float16*)p.W + p.w_sZ * z;
+    const int nk = p.Ktot / RK;
+    const bool ident = p.ktab_identity != 0;
+    if (!ident) {
+        for (int i = tid; i < nk * 4; i += 512) kt_lds[i] = p.ktab[i];
+        __syncthreads();
+    }
+
+    const int ldrow = tid >> 2;                          // + 128*i
+    const int q = (tid & 3) ^ ((ldrow >> 1) & 2);        // logical K-chunk this lane fetches (swizzled source)
+    long safe0 = (long)p.h0 * p.a_sH[0] + (long)p.w0 * p.a_sW[0] + p.a_c0[0];
+    long safe1 = (long)p.h0 * p.a_sH[1] + (long)p.w0 * p.a_sW[1] + p.a_c0[1];
+    unsigned rb0[NA], rb1[NA];
+    const RowDecomp rd(p.Wg, p.Hg);
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        unsigned m = m0 + ldrow + 128 * i;
+        unsigned w, h, b;
+        rd(m, b, h, w);
+        bool ok = m < (unsigned)p.M && (int)h >= p.h0 && (int)h < p.h1 && (int)w >= p.w0 && (int)w < p.w1;
+        long r0 = ok ? (long)b * p.a_sB[0] + (long)h * p.a_sH[0] + (long)w * p.a_sW[0] + p.a_c0[0] : safe0;
+        long r1 = ok ? (long)b * p.a_sB[1] + (long)h * p.a_sH[1] + (long)w * p.a_sW[1] + p.a_c0[1] : safe1;
+        rb0[i] = (unsigned)r0;
+        rb1[i] = (unsigned)r1;
+    }
+    const _Float16* wrow[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) wrow[i] = Wp + (long)(n0 + ldrow + 128 * i) * p.Ktot + q * 8;
+
+    const int fr = lane & 15, fq = lane >> 4;
+    const int phys = fq ^ ((fr >> 1) & 2);
+    const unsigned lds0 = (unsigned)(unsigned long)LDS_PTR(dsmem);
+    const unsigned uoffA = ((wm * TM + fr) * 4 + phys) * 16;
+    const unsigned uoffB = BM * RK * 2 + ((wn * TN + fr) * 4 + phys) * 16;
+
+    f32x4 acc[NI][MI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto issue = [&](int kt) {
+        const int kq = ident ? kt * 4 + q : kt_lds[kt * 4 + q];
+        char* st = dsmem + (kt % RSTAGES) * STAGE;
+        const bool s1 = kq < 0;
+        const unsigned ko = (unsigned)kq & 0x7fffffffu;
+        const _Float16* base = s1 ? A1 : A0;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const _Float16* g = base + ((unsigned long)((s1 ? rb1[i] : rb0[i]) + ko)) * 8;
+            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(g), LDS_PTR(st + (wv * 64 + 512 * i) * 16), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(wrow[i] + kt * RK), LDS_PTR(st + BM * RK * 2 + (wv * 64 + 512 * i) * 16), 16, 0, 0);
+    };
+#pragma unroll
+    for (int t = 0; t < RSTAGES - 1; ++t)
+        if (t < nk) issue(t);
+    for (int kt = 0; kt < nk; ++kt) {
+        // retire tile kt only: up to two younger tiles stay in flight across the barrier
+        if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NLOAD) : "memory");
+        else if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOAD) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                          // tile kt visible to all; stage (kt-1)%4 free
+        if (kt + RSTAGES - 1 < nk) issue(kt + RSTAGES - 1);
+        const unsigned sbase = lds0 + (kt % RSTAGES) * STAGE;
+        f16x8 b[NI], a[2][2];
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) DS_READ128(b[ni], sbase + uoffB, ni * 1024);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) DS_READ128(a[0][e], sbase + uoffA, e * 1024);
+#pragma unroll
+        for (int pr = 0; pr < MI / 2; ++pr) {
+            const int cur = pr & 1, nxt = cur ^ 1;
+            if (pr + 1 < MI / 2) {
+#pragma unroll
+                for (int e = 0; e < 2; ++e) DS_READ128(a[nxt][e], sbase + uoffA, (2 * (pr + 1) + e) * 1024);
+                LGKM_WAIT(2);
+            } else {
+                LGKM_WAIT(0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+                    acc[ni][2 * pr + e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[ni], a[cur][e], acc[ni][2 * pr + e], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    gemm_epilogue<MI, NI>(p, acc, m0 + wm * TM, n0 + wn * TN, fr, fq, z);
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch_ring(const advh_gemm_desc& d, hipStream_t s) {
+    const int tilesM = (d.M + BM - 1) / BM, tilesN = (d.N + BN - 1) / BN;
+    if (tilesN * BN > d.w_rows || d.Ktot / 8 > RING_KTAB_MAX) return ADVH_EINVAL;
+    dim3 grid(tilesM * tilesN, 1, d.nz > 0 ? d.nz : 1);
+    hipLaunchKernelGGL((gemm_f16_ring_kernel<BM, BN, WM, WN>), grid, dim3(512), RSTAGES * (BM + BN) * RK * 2 + RING_KTAB_MAX * 4, s, d);
+    return ADVH_LAUNCH_CHECK();
+}
+
 }  // namespace advh
 
 using namespace advh;
@@ -413,6 +547,7 @@ int advh_init_rest() {
     const int maxlds = 160 * 1024;
     if (hipFuncSetAttribute((const void*)gemm_f16_pipe_kernel<256, 256, 2, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, maxlds) != hipSuccess) return ADVH_ELAUNCH;
     if (hipFuncSetAttribute((const void*)gemm_f16_pipe_kernel<256, 128, 4, 2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, maxlds) != hipSuccess) return ADVH_ELAUNCH;
+    if (hipFuncSetAttribute((const void*)gemm_f16_ring_kernel<256, 256, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, maxlds) != hipSuccess) return ADVH_ELAUNCH;
     return ADVH_OK;
 }
 
@@ -431,6 +566,7 @@ extern "C" int advh_gemm_f16(const advh_gemm_desc* d, int tile, advh_stream_t st
         case ADVH_TILE_256x128_W4: return launch<256, 128, 2, 2>(*d, s);
         case ADVH_TILE_128x256_W4: return launch<128, 256, 2, 2>(*d, s);
         case ADVH_TILE_256x256: return launch_pipe<256, 256, 2, 4, 2>(*d, s);
+        case ADVH_TILE_256x256_RING: return launch_ring<256, 256, 2, 4>(*d, s);
         case ADVH_TILE_256x128: return launch_pipe<256, 128, 4, 2, 3>(*d, s);
         default: return ADVH_EINVAL;
     }
