@@ -63,15 +63,21 @@ class HipAttribution:
         per = max(1, (internal_batch_size or 128) // B)            # whole steps per chunk
         total = torch.zeros_like(x)
         lib = _lib.lib()
-        for s0 in range(0, n_steps, per):
-            ns = min(per, n_steps - s0)
-            a = torch.tensor(np.repeat(alphas[s0:s0 + ns], B), dtype=torch.float32, device=x.device)
-            scaled = torch.empty((ns * B, L), dtype=torch.float32, device=x.device)
+        per = min(per, n_steps)
+        npad = -(-n_steps // per) * per                              # every chunk has the same shape: one workspace
+        alphas = np.concatenate([alphas, np.full(npad - n_steps, alphas[-1])])
+        steps = np.concatenate([steps, np.zeros(npad - n_steps)])    # padding steps carry zero weight
+        a_all = torch.tensor(np.repeat(alphas, B), dtype=torch.float32, device=x.device)
+        w_all = torch.tensor(np.repeat(steps, B), dtype=torch.float32, device=x.device)
+        scaled = torch.empty((per * B, L), dtype=torch.float32, device=x.device)
+        for s0 in range(0, npad, per):
+            ns = per
+            a = a_all[s0 * B:(s0 + ns) * B]
             _lib.check(lib.advh_scale_rows(x.data_ptr(), B, a.data_ptr(), scaled.data_ptr(), ns * B, L, 0, _st()), "advh_scale_rows")
             self.eg.forward(scaled)
             g = self.eg.backward(self.loss_scale)                    # [ns*B, L], step-major
             for k in range(ns):
-                wk = torch.full((B,), float(steps[s0 + k]), dtype=torch.float32, device=x.device)
+                wk = w_all[(s0 + k) * B:(s0 + k + 1) * B]
                 _lib.check(lib.advh_scale_rows(g[k * B:(k + 1) * B].data_ptr(), B, wk.data_ptr(), total.data_ptr(), B, L, 1, _st()),
                            "advh_scale_rows")
         return self._finalize(total, x, 1)

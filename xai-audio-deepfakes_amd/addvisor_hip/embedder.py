@@ -67,6 +67,7 @@ class HipEmbedder:
         if self.coef.numel() != cfg.hidden_size:
             raise ValueError("logreg coef_ must have hidden_size entries")
         self._ws: Dict[Tuple[int, int, int], dict] = {}
+        self._wcache: dict = {}                    # packed fp16 weights, shared by the plans of every batch shape
 
     # ------------------------------------------------------------------ planning (once per batch shape)
     def _lengths(self, L: int) -> List[int]:
@@ -123,33 +124,40 @@ class HipEmbedder:
         for i in range(1, nfe):
             p = f"feature_extractor.conv_layers.{i}.conv."
             fe_plans.append(G.plan_conv1d_cl(B, P[i - 1], P[i], Ls[i], sd[p + "weight"], sd.get(p + "bias"),
-                                             strides[i], act=act, compact_out=(i == nfe - 1), device=dev))
+                                             strides[i], act=act, compact_out=(i == nfe - 1), device=dev,
+                                             cache=(self._wcache, ("fe", i))))
         ws["fe_plans"] = fe_plans
         ws["proj"] = G.plan_linear(M, sd["feature_projection.projection.weight"],
-                                   sd["feature_projection.projection.bias"], device=dev)
+                                   sd["feature_projection.projection.bias"], device=dev, cache=(self._wcache, "proj"))
         # positional conv: weight_norm folded (modeling_wav2vec2.py:326-357), one GEMM batched over groups
         g0 = sd["encoder.pos_conv_embed.conv.parametrizations.weight.original0"]
         v0 = sd["encoder.pos_conv_embed.conv.parametrizations.weight.original1"]
-        wpos = g0 * v0 / v0.pow(2).sum(dim=(0, 1), keepdim=True).sqrt()           # [H, Cg, K]
-        w2 = wpos.view(Gp, Cg, Cg, K).permute(0, 1, 3, 2).reshape(Gp, Cg, K * Cg)  # [g][n][(k, ci)]
+        w2 = lambda: (g0 * v0 / v0.pow(2).sum(dim=(0, 1), keepdim=True).sqrt()).view(Gp, Cg, Cg, K) \
+            .permute(0, 1, 3, 2).reshape(Gp, Cg, K * Cg)                            # [g][n][(k, ci)]
         cc = Cg // 8
         ws["pos"] = G.GemmPlan(M=M, N=Cg, w2=w2, ktab=np.arange(K * cc, dtype=np.int64),
                                sources=[G.Source((T + K) * cc, 0, cc, 0, sZ=B * (T + K) * cc)], Hg=1, Wg=T,
                                window=(0, 1, 0, T), halo_zero=False, out=(T * H, 0, H, 0), n_div=G.round_up(Cg, 4),
                                o_sZ=Cg, nz=Gp, bias=sd["encoder.pos_conv_embed.conv.bias"], bias_sZ=Cg, act="gelu",
-                               device=dev)
+                               device=dev, cache=(self._wcache, "pos"))
         layers = []
         for l in range(self.nl):
             p = f"encoder.layers.{l}."
-            wqkv = torch.cat([sd[p + f"attention.{n}_proj.weight"] for n in ("q", "k", "v")], 0)
-            bqkv = torch.cat([sd[p + f"attention.{n}_proj.bias"] for n in ("q", "k", "v")], 0)
+            if ("qkv", l) in self._wcache:                 # packed already: only the shapes are needed
+                wqkv = torch.empty(3 * H, H, device="meta")
+                bqkv = torch.empty(3 * H, device="meta")
+            else:
+                wqkv = torch.cat([sd[p + f"attention.{n}_proj.weight"] for n in ("q", "k", "v")], 0)
+                bqkv = torch.cat([sd[p + f"attention.{n}_proj.bias"] for n in ("q", "k", "v")], 0)
+            c = lambda name: (self._wcache, (name, l))
             layers.append(dict(
-                qkv=G.plan_linear(M, wqkv, bqkv, device=dev),
-                out=G.plan_linear(M, sd[p + "attention.out_proj.weight"], sd[p + "attention.out_proj.bias"], device=dev),
+                qkv=G.plan_linear(M, wqkv, bqkv, device=dev, cache=c("qkv")),
+                out=G.plan_linear(M, sd[p + "attention.out_proj.weight"], sd[p + "attention.out_proj.bias"], device=dev,
+                                  cache=c("out")),
                 ff1=G.plan_linear(M, sd[p + "feed_forward.intermediate_dense.weight"],
-                                  sd[p + "feed_forward.intermediate_dense.bias"], act="gelu", device=dev),
+                                  sd[p + "feed_forward.intermediate_dense.bias"], act="gelu", device=dev, cache=c("ff1")),
                 ff2=G.plan_linear(M, sd[p + "feed_forward.output_dense.weight"],
-                                  sd[p + "feed_forward.output_dense.bias"], device=dev)))
+                                  sd[p + "feed_forward.output_dense.bias"], device=dev, cache=c("ff2"))))
         ws["layers"] = layers
         ws["flops"] = (sum(p.flops for p in fe_plans) + ws["proj"].flops + ws["pos"].flops
                        + sum(sum(pl.flops for pl in lay.values()) for lay in layers)

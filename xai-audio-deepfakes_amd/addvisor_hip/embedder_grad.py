@@ -23,7 +23,7 @@ from . import _lib, gemm as G
 from .embedder import HipEmbedder
 
 
-def plan_conv1d_dgrad(B: int, P_out: int, weight: torch.Tensor, stride: int, device=None) -> G.GemmPlan:
+def plan_conv1d_dgrad(B: int, P_out: int, weight: torch.Tensor, stride: int, device=None, cache=None) -> G.GemmPlan:
     """Input gradient of the channels-last Conv1d of ``gemm.plan_conv1d_cl`` (no padding): position
     ``u = s*q + phase`` of the input receives ``sum_{i} dZ[q - (nt-1) + i] . W[:, :, phase + s*(nt-1-i)]``
     (nt = ceil(k/s) taps), so the layer is a GEMM over rows q with K = nt*Cout (nt adjacent dZ rows = one
@@ -33,16 +33,18 @@ def plan_conv1d_dgrad(B: int, P_out: int, weight: torch.Tensor, stride: int, dev
     s = stride
     nt = -(-k // s)
     assert Cout % 8 == 0 and Cin % 4 == 0
-    w2 = torch.zeros(s * Cin, nt * Cout)
-    for phase in range(s):
-        for i in range(nt):
-            j = phase + s * (nt - 1 - i)
-            if j < k:
-                w2[phase * Cin:(phase + 1) * Cin, i * Cout:(i + 1) * Cout] = weight[:, :, j].t()
+    def w2():
+        m = torch.zeros(s * Cin, nt * Cout)
+        for phase in range(s):
+            for i in range(nt):
+                j = phase + s * (nt - 1 - i)
+                if j < k:
+                    m[phase * Cin:(phase + 1) * Cin, i * Cout:(i + 1) * Cout] = weight[:, :, j].t()
+        return m[None]
     cc = Cout // 8
-    return G.GemmPlan(M=B * P_out, N=s * Cin, w2=w2[None], ktab=np.arange(nt * cc, dtype=np.int64),
+    return G.GemmPlan(M=B * P_out, N=s * Cin, w2=w2, ktab=np.arange(nt * cc, dtype=np.int64),
                       sources=[G.Source(P_out * cc, 0, cc, 0)], Hg=1, Wg=P_out, window=(0, 1, 0, P_out), halo_zero=False,
-                      out=(P_out * s * Cin, 0, s * Cin, 0), device=device), nt
+                      out=(P_out * s * Cin, 0, s * Cin, 0), device=device, cache=cache), nt
 
 
 class EmbedderGrad:
@@ -52,6 +54,7 @@ class EmbedderGrad:
         self.layer_mode = emb.layer_mode                       # "layer" feature extractor (wav2vec2-large / xls-r)
         self.stable = self.cfg.do_stable_layer_norm            # pre-LN encoder
         self._ws: Dict[Tuple[int, int], dict] = {}
+        self._wcache: dict = {}
 
     # ------------------------------------------------------------------ buffers and plans
     def _workspace(self, B: int, L: int) -> dict:
@@ -104,34 +107,39 @@ class EmbedderGrad:
         w["dxh"] = z(B, L, dt=f32)
         w["wpart"] = z(B, -(-L // 2048), 2, dt=f32)
         # backward plans -----------------------------------------------------------------
-        lin = lambda wt, **kw: G.plan_linear(M, wt, None, device=dev, **kw)
+        wc = self._wcache
+        lin = lambda wt, key: G.plan_linear(M, wt, None, device=dev, cache=(wc, key))
         layers = []
         for l in range(nl):
             p = f"encoder.layers.{l}."
-            wqkv = torch.cat([sd[p + f"attention.{n}_proj.weight"] for n in ("q", "k", "v")], 0)
-            layers.append(dict(ff2=lin(sd[p + "feed_forward.output_dense.weight"].t()),
-                               ff1=lin(sd[p + "feed_forward.intermediate_dense.weight"].t()),
-                               out=lin(sd[p + "attention.out_proj.weight"].t()), qkv=lin(wqkv.t())))
+            if ("qkv", l) in wc:
+                wqkv = torch.empty(3 * H, H, device="meta")
+            else:
+                wqkv = torch.cat([sd[p + f"attention.{n}_proj.weight"] for n in ("q", "k", "v")], 0)
+            layers.append(dict(ff2=lin(sd[p + "feed_forward.output_dense.weight"].t(), ("ff2", l)),
+                               ff1=lin(sd[p + "feed_forward.intermediate_dense.weight"].t(), ("ff1", l)),
+                               out=lin(sd[p + "attention.out_proj.weight"].t(), ("out", l)), qkv=lin(wqkv.t(), ("qkv", l))))
         w["layers"] = layers
-        w["proj"] = lin(sd["feature_projection.projection.weight"].t())
+        w["proj"] = lin(sd["feature_projection.projection.weight"].t(), "proj")
         K, Gp = cfg.num_conv_pos_embeddings, cfg.num_conv_pos_embedding_groups
         Cg, cc = H // Gp, H // Gp // 8
         g0 = sd["encoder.pos_conv_embed.conv.parametrizations.weight.original0"]
         v0 = sd["encoder.pos_conv_embed.conv.parametrizations.weight.original1"]
-        wpos = (g0 * v0 / v0.pow(2).sum(dim=(0, 1), keepdim=True).sqrt()).view(Gp, Cg, Cg, K)        # [g][co][ci][k]
-        w2b = wpos.flip(3).permute(0, 2, 3, 1).reshape(Gp, Cg, K * Cg)                                 # [g][ci][(k', co)]
+        w2b = lambda: (g0 * v0 / v0.pow(2).sum(dim=(0, 1), keepdim=True).sqrt()).view(Gp, Cg, Cg, K) \
+            .flip(3).permute(0, 2, 3, 1).reshape(Gp, Cg, K * Cg)                   # [g][ci][(k', co)], taps flipped
         w["pos"] = G.GemmPlan(M=M, N=Cg, w2=w2b, ktab=np.arange(K * cc, dtype=np.int64),
                               sources=[G.Source((T + K) * cc, 0, cc, 0, sZ=B * (T + K) * cc)], Hg=1, Wg=T,
                               window=(0, 1, 0, T), halo_zero=False, out=(T * H, 0, H, 0), n_div=G.round_up(Cg, 4),
-                              o_sZ=Cg, nz=Gp, device=dev)
+                              o_sZ=Cg, nz=Gp, device=dev, cache=(wc, "pos"))
         fe = []
         for i in range(1, nfe):
-            plan, nt = plan_conv1d_dgrad(B, P[i], sd[f"feature_extractor.conv_layers.{i}.conv.weight"], cfg.conv_stride[i], dev)
+            plan, nt = plan_conv1d_dgrad(B, P[i], sd[f"feature_extractor.conv_layers.{i}.conv.weight"], cfg.conv_stride[i], dev,
+                                         cache=(wc, ("fe", i)))
             fe.append((plan, nt))
         w["fe"] = fe
         w0t = torch.zeros(16, C[0])
         w0t[:10] = sd["feature_extractor.conv_layers.0.conv.weight"].reshape(C[0], 10).t()
-        w["g_plan"] = G.plan_linear(B * P[0], w0t, None, device=dev)
+        w["g_plan"] = G.plan_linear(B * P[0], w0t, None, device=dev, cache=(wc, "w0t"))
         self._ws[key] = w
         return w
 

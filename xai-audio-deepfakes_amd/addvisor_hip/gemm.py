@@ -103,30 +103,40 @@ class GemmPlan:
                  out: Tuple[int, int, int, int], n_div: Optional[int] = None, o_sNhi: int = 0,
                  o_sZ: int = 0, nz: int = 1, bias: Optional[torch.Tensor] = None, act: str = "none",
                  slope: float = 0.0, device=None, w_sZ: Optional[int] = None, bias_sZ: int = 0,
-                 slope2: float = 0.0, phase: Tuple[int, int, int] = (0, 0, 0)):
-        """``w2``: fp32 ``[nz, N, K]`` (K = 8 * len(ktab) before padding); ``ktab``: int64 chunk offsets with
-        bit 31 as source selector; ``out`` = (o_sB, o_sH, o_sW, o_c0) in elements."""
-        assert w2.dim() == 3 and w2.shape[0] == nz and w2.shape[1] == N
-        K = w2.shape[2]
-        assert K == 8 * len(ktab), (K, len(ktab))
+                 slope2: float = 0.0, phase: Tuple[int, int, int] = (0, 0, 0), cache: Optional[tuple] = None):
+        """``w2``: fp32 ``[nz, N, K]`` (K = 8 * len(ktab) before padding) or a zero-argument callable returning it
+        (only called when the packed weight is not in ``cache``); ``ktab``: int64 chunk offsets with bit 31 as
+        source selector; ``out`` = (o_sB, o_sH, o_sW, o_c0) in elements.  ``cache = (dict, key)`` shares the
+        packed fp16 weight / bias device tensors between plans of different batch shapes (the weight of a layer
+        does not depend on the batch)."""
+        K = 8 * len(ktab)
         Kp = round_up(K, BK)
         tile, BN = pick_tile(N)
         w_rows = round_up(N, 256)        # any tile's BN divides 256: the tile can be re-chosen later (autotune)
-        wp = torch.zeros((nz, w_rows, Kp), dtype=torch.float16)
-        wp[:, :N, :K] = w2.to(torch.float16)
+        store, ckey = cache if cache is not None else (None, None)
+        hit = store.get(ckey) if store is not None else None
+        if hit is None:
+            w2t = w2() if callable(w2) else w2
+            assert w2t.dim() == 3 and w2t.shape[0] == nz and w2t.shape[1] == N and w2t.shape[2] == K, (w2t.shape, nz, N, K)
+            wp = torch.zeros((nz, w_rows, Kp), dtype=torch.float16)
+            wp[:, :N, :K] = w2t.to(torch.float16)
+            wd = wp.to(device) if device is not None else wp
+            bd = None
+            if bias is not None:
+                assert bias.numel() == nz * N or bias_sZ == 0
+                bd = bias.to(torch.float32).contiguous()
+                bd = bd.to(device) if device is not None else bd
+            hit = (wd, bd)
+            if store is not None:
+                store[ckey] = hit
         kt = np.concatenate([ktab, np.full((Kp - K) // 8, ktab[0], dtype=np.int64)]).astype(np.int64)
         assert (kt & 0x7FFFFFFF).max() < 2 ** 31
         self.ktab_host = kt
         self.K, self.Kp, self.tile, self.BN = K, Kp, tile, BN
         self.device = device
-        self.w = wp.to(device) if device is not None else wp
+        self.w, self.bias = hit
         kt32 = torch.from_numpy(kt.astype(np.uint32).view(np.int32).copy())
         self.ktab = kt32.to(device) if device is not None else kt32
-        self.bias = None
-        if bias is not None:
-            assert bias.numel() == nz * N or bias_sZ == 0
-            b = bias.to(torch.float32).contiguous()
-            self.bias = b.to(device) if device is not None else b
         d = GemmDesc()
         d.M, d.N, d.Ktot, d.w_rows = M, N, Kp, w_rows
         d.Hg, d.Wg = Hg, Wg
@@ -240,30 +250,31 @@ class FMap:
 
 
 def plan_linear(M: int, weight: torch.Tensor, bias: Optional[torch.Tensor], *, lda: Optional[int] = None,
-                ldo: Optional[int] = None, o_c0: int = 0, act: str = "none", device=None) -> GemmPlan:
+                ldo: Optional[int] = None, o_c0: int = 0, act: str = "none", device=None, cache=None) -> GemmPlan:
     """``out[m, :N] = act(A[m, :K] @ weight.T + bias)``; nn.Linear (modeling_wav2vec2.py:422-572)."""
     N, K = weight.shape
     assert K % 8 == 0
     lda = K if lda is None else lda
     ldo = N if ldo is None else ldo
     assert lda % 8 == 0 and ldo % 4 == 0
-    return GemmPlan(M=M, N=N, w2=weight[None].float(), ktab=np.arange(K // 8, dtype=np.int64),
+    return GemmPlan(M=M, N=N, w2=lambda: weight[None].float(), ktab=np.arange(K // 8, dtype=np.int64),
                     sources=[Source(0, 0, lda // 8, 0)], Hg=1, Wg=M, window=(0, 1, 0, M), halo_zero=False,
-                    out=(0, 0, ldo, o_c0), bias=bias, act=act, device=device)
+                    out=(0, 0, ldo, o_c0), bias=bias, act=act, device=device, cache=cache)
 
 
 def plan_conv1d_cl(B: int, P_in: int, P_out: int, L_out: int, weight: torch.Tensor, bias: Optional[torch.Tensor],
-                   stride: int, *, act: str = "gelu", compact_out: bool = False, device=None) -> GemmPlan:
+                   stride: int, *, act: str = "gelu", compact_out: bool = False, device=None, cache=None) -> GemmPlan:
     """Channels-last Conv1d (no padding) as an overlapping-row GEMM: wav2vec2 feature-encoder layers 1-6
     (modeling_wav2vec2.py:254-323).  Input ``[B, P_in, Cin]``, rows >= L_in are zero filler; output
     ``[B, P_out, Cout]`` with rows >= L_out written as zeros, or ``[B, L_out, Cout]`` if ``compact_out``."""
     Cout, Cin, k = weight.shape
     assert Cin % 8 == 0
-    w2 = weight.permute(0, 2, 1).reshape(1, Cout, k * Cin).float()          # K order: (tap, channel)
+    w2 = lambda: weight.permute(0, 2, 1).reshape(1, Cout, k * Cin).float()  # K order: (tap, channel)
     out = (L_out * Cout, 0, Cout, 0) if compact_out else (P_out * Cout, 0, Cout, 0)
     return GemmPlan(M=B * P_out, N=Cout, w2=w2, ktab=np.arange(k * Cin // 8, dtype=np.int64),
                     sources=[Source(P_in * Cin // 8, 0, stride * Cin // 8, 0)], Hg=1, Wg=P_out,
-                    window=(0, 1, 0, L_out), halo_zero=not compact_out, out=out, bias=bias, act=act, device=device)
+                    window=(0, 1, 0, L_out), halo_zero=not compact_out, out=out, bias=bias, act=act, device=device,
+                    cache=cache)
 
 
 def plan_conv2d(srcs: Sequence[FMap], dst: FMap, weight: torch.Tensor, bias: Optional[torch.Tensor], *,
