@@ -250,6 +250,30 @@ int advh_attr_finalize(const float* g, const float* x, float* out, int mode, int
 int advh_time_mask(const float* attr, float* mask, float* wave_in, float* wave_out, const float* wave, int B, int64_t n,
                    advh_stream_t stream);
 
+/* ---- LDS line-tile convolution for narrow layers (C_in = C_out = C in {32, 64}) -------------------------------
+ * out[m][co] = act(bias[co] + sum_t sum_ci W[t][co][ci] * X[m + toff[t]][ci]) (+ resid[m][co]) over the M rows of a
+ * zero-haloed channels-last fp16 map; rows outside the window (h0..h1, w0..w1 of the (Hg, Wg) row grid) are
+ * written as zeros, so the output map keeps a zero halo.  X, resid, out_h, out_h2 share one geometry [M][C].
+ * Replaces the HiFi-GAN ResBlock1 Conv1d layers of the 64- and 32-channel stages (speechbrain HifiganGenerator via
+ * hifigan.py:106-110, 180): toff[t] = (t - (k-1)/2) * dilation.  Weights stay resident in LDS (<= 160 KiB with the
+ * double-buffered line buffer: advh_conv_taps_lds_bytes), HBM traffic is input once + output once.               */
+typedef struct advh_taps_desc {
+    const void* X;        /* fp16 [M][C]                                                          */
+    const void* W;        /* fp16 [ntap][C_out][C_in]                                             */
+    const float* bias;    /* [C] or NULL                                                          */
+    const void* resid;    /* fp16 [M][C] or NULL (added after the activation)                     */
+    void* out_h;          /* fp16 [M][C]                                                          */
+    void* out_h2;         /* fp16 [M][C] or NULL: LeakyReLU(slope2) of the value stored in out_h   */
+    int M, Hg, Wg, h0, h1, w0, w1;
+    int ntap;
+    int toff[16];
+    int act;              /* ADVH_ACT_NONE | ADVH_ACT_LEAKY */
+    float slope, slope2;
+} advh_taps_desc;
+int advh_conv_taps_tile(int C, int ntap, int span);       /* positions per workgroup tile (128/192/256); 0 = does not fit */
+int advh_conv_taps_lds_bytes(int C, int ntap, int span);  /* weights + two line buffers; -1 = does not fit           */
+int advh_conv_taps_f16(const advh_taps_desc* d, int C, advh_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

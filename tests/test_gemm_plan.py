@@ -127,3 +127,40 @@ def test_lds_swizzles_are_conflict_free():
     for g in groups:                                    # BK = 32: rows of 4 chunks
         slots = {((l & 15) * 64 + (((l >> 4) ^ (((l & 15) >> 1) & 2)) * 16)) % 256 // 16 for l in g}
         assert len(slots) == 16
+
+
+def test_conv1d_taps_plan():
+    """Weights-in-LDS line-tile plan (csrc/conv_taps.hip): same layer as plan_conv1d_same for C in {32, 64}."""
+    B, T = 2, 37
+    for C_, k, d in ((32, 3, 1), (64, 7, 3), (32, 11, 5), (64, 11, 5), (64, 3, 5)):
+        x = rnd(B, C_, T)
+        src, dst = G.Map1D(B, T, C_, 32), G.Map1D(B, T, C_, 32)
+        src.t = torch.zeros(B, src.P, C_, dtype=torch.float16)
+        src.interior()[:] = x.transpose(1, 2).half()
+        w, b = rnd(C_, C_, k) * 0.1, rnd(C_)
+        assert G.taps_supported(src, dst, w, d)
+        p = G.plan_conv1d_taps(src, dst, w, b, dilation=d, act="leaky", slope=0.1)
+        assert 0 < G.taps_lds_bytes(C_, k, (k - 1) * d) <= 160 * 1024
+        res = rnd(B, src.P, C_).half()
+        out = G.replay_taps_on_cpu(p, src.t, res).view(B, dst.P, C_)
+        ref = F.leaky_relu(F.conv1d(x.half().float(), w.half().float(), b, padding=(k - 1) * d // 2, dilation=d), 0.1)
+        ref = ref.transpose(1, 2) + res[:, 32:32 + T].float()
+        assert torch.allclose(out[:, 32:32 + T], ref, atol=2e-3)
+        assert (out[:, :32] == 0).all() and (out[:, 32 + T:] == 0).all()
+    assert not G.taps_supported(G.Map1D(1, 8, 128, 32), G.Map1D(1, 8, 128, 32), rnd(128, 128, 3), 1)
+    assert not G.taps_supported(G.Map1D(1, 8, 64, 32), G.Map1D(1, 8, 64, 16), rnd(64, 64, 3), 1)
+
+
+def test_line_tile_swizzles_are_conflict_free():
+    """conv_taps.hip reads 16 consecutive LDS rows starting at ANY row (tap offsets shift the base): the swizzles
+    chunk ^= row & 7 (128-byte rows) and chunk ^= (row >> 1) & 2 (64-byte rows) stay conflict-free."""
+    groups = [[0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27], [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31],
+              [32, 33, 34, 35, 44, 45, 46, 47, 52, 53, 54, 55, 56, 57, 58, 59], [36, 37, 38, 39, 40, 41, 42, 43, 48, 49, 50, 51, 60, 61, 62, 63]]
+    for base in range(64):
+        for ks in (0, 1):
+            for g in groups:
+                slots = {((base + (l & 15)) * 128 + (((ks * 4 + (l >> 4)) ^ ((base + (l & 15)) & 7)) * 16)) % 256 // 16 for l in g}
+                assert len(slots) == 16
+        for g in groups:
+            slots = {((base + (l & 15)) * 64 + (((l >> 4) ^ (((base + (l & 15)) >> 1) & 2)) * 16)) % 256 // 16 for l in g}
+            assert len(slots) == 16

@@ -116,3 +116,31 @@ def test_convT2d(gpu_device, stride, Cin, Cout):
     ref = F.conv_transpose2d(x.half().float(), w.half().float(), b, stride=stride)
     close(dst.interior()[..., 8:].permute(0, 3, 1, 2), ref)
     assert (dst.interior()[..., :8] == 0).all()
+
+
+@pytest.mark.parametrize("Cn,k,d,B,T", [(64, 3, 1, 2, 300), (64, 11, 5, 3, 1000), (32, 7, 3, 2, 777), (32, 11, 5, 1, 4096),
+                                        (64, 7, 1, 1, 50), (32, 3, 5, 5, 129)])
+def test_conv1d_line_tile(gpu_device, Cn, k, d, B, T):
+    """csrc/conv_taps.hip (weights resident in LDS) against the CPU replay of its descriptor, incl. residual, the
+    pre-activated second output and zeroed halo rows."""
+    _lib.init()
+    g = torch.Generator().manual_seed(Cn * k + d)
+    src, dst = G.Map1D(B, T, Cn, 32), G.Map1D(B, T, Cn, 32)
+    src.t = torch.zeros(B, src.P, Cn, dtype=torch.float16)
+    src.interior()[:] = rnd(g, B, T, Cn).half()
+    w, b = rnd(g, Cn, Cn, k) / (Cn * k) ** 0.5, rnd(g, Cn)
+    res = rnd(g, B, src.P, Cn).half()
+    p = G.plan_conv1d_taps(src, dst, w, b, dilation=d, act="leaky", slope=0.1, slope2=0.2, device=gpu_device)
+    xd, rd = src.t.to(gpu_device), res.to(gpu_device)
+    o1 = torch.full((B, dst.P, Cn), float("nan"), dtype=torch.float16, device=gpu_device)
+    o2 = torch.full_like(o1, float("nan"))
+    p.run(xd, out_h=o1, resid=rd, out_h2=o2)
+    torch.cuda.synchronize()
+    ref = G.replay_taps_on_cpu(p, src.t, res).view(B, dst.P, Cn)
+    close(o1, ref)
+    close(o2, F.leaky_relu(ref, 0.2))
+    assert (o1[:, :32] == 0).all() and (o1[:, 32 + T:] == 0).all()
+    ref_gemm = G.plan_conv1d_same(src, dst, w, b, dilation=d, act="leaky", slope=0.1, slope2=0.2, device=gpu_device)
+    o3 = torch.empty_like(o1)
+    ref_gemm.run(xd, out_h=o3, resid=rd)
+    close(o1, o3.cpu())

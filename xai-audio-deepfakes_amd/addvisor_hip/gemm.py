@@ -420,6 +420,117 @@ def plan_conv1d_same(src: Map1D, dst: Map1D, weight: torch.Tensor, bias: Optiona
                     bias=bias, act=act, slope=slope, slope2=slope2, device=device)
 
 
+
+# ------------------------------------------------------------------------------------ LDS line-tile conv (narrow C)
+class TapsDesc(C.Structure):
+    """Mirror of ``advh_taps_desc`` (include/addvisor_hip.h)."""
+    _fields_ = [("X", C.c_void_p), ("W", C.c_void_p), ("bias", C.c_void_p), ("resid", C.c_void_p),
+                ("out_h", C.c_void_p), ("out_h2", C.c_void_p),
+                ("M", C.c_int), ("Hg", C.c_int), ("Wg", C.c_int), ("h0", C.c_int), ("h1", C.c_int),
+                ("w0", C.c_int), ("w1", C.c_int), ("ntap", C.c_int), ("toff", C.c_int * 16),
+                ("act", C.c_int), ("slope", C.c_float), ("slope2", C.c_float)]
+
+
+TAPS_MAX_LDS = 160 * 1024
+
+
+def taps_tile(Cn: int, ntap: int, span: int) -> int:
+    """Host copy of ``advh_conv_taps_tile``: positions per workgroup tile (64 * column tiles per wavefront), the
+    widest whose weights + two line buffers fit in LDS; 0 = unsupported."""
+    for nj in (4, 3, 2):
+        if ntap * Cn * Cn * 2 + 2 * (((64 * nj + span) * (Cn // 8) + 63) // 64 * 64) * 16 <= TAPS_MAX_LDS:
+            return 64 * nj
+    return 0
+
+
+def taps_lds_bytes(Cn: int, ntap: int, span: int) -> int:
+    """Host copy of ``advh_conv_taps_lds_bytes`` (weights + double-buffered line buffer)."""
+    tt = taps_tile(Cn, ntap, span)
+    return -1 if not tt else ntap * Cn * Cn * 2 + 2 * (((tt + span) * (Cn // 8) + 63) // 64 * 64) * 16
+
+
+class TapsPlan:
+    """One launch of ``advh_conv_taps_f16``: a "same" convolution expressed as taps at constant row offsets of one
+    zero-haloed channels-last geometry shared by input, residual and outputs."""
+
+    def __init__(self, *, M: int, Cn: int, w_taps: torch.Tensor, toff: Sequence[int], Hg: int, Wg: int,
+                 window: Tuple[int, int, int, int], bias: Optional[torch.Tensor], act: str = "none",
+                 slope: float = 0.0, slope2: float = 0.0, device=None):
+        ntap = len(toff)
+        assert w_taps.shape == (ntap, Cn, Cn) and Cn in (32, 64) and 0 < ntap <= 16
+        assert taps_tile(Cn, ntap, max(max(toff), 0) - min(min(toff), 0)) > 0
+        self.Cn, self.device = Cn, device
+        self.w = w_taps.to(torch.float16).contiguous()
+        self.bias = None if bias is None else bias.to(torch.float32).contiguous()
+        if device is not None:
+            self.w = self.w.to(device)
+            self.bias = None if self.bias is None else self.bias.to(device)
+        d = TapsDesc()
+        d.M, d.Hg, d.Wg = M, Hg, Wg
+        d.h0, d.h1, d.w0, d.w1 = window
+        d.ntap = ntap
+        for i, t in enumerate(toff):
+            d.toff[i] = int(t)
+        d.act, d.slope, d.slope2 = ACT[act], slope, slope2
+        self.desc = d
+        valid = (window[1] - window[0]) * (window[3] - window[2]) * (M // (Hg * Wg))
+        self.flops = 2.0 * valid * Cn * Cn * ntap
+
+    def run(self, A0: torch.Tensor, A1=None, *, out_h: torch.Tensor, resid: Optional[torch.Tensor] = None,
+            out_h2: Optional[torch.Tensor] = None, stream: Optional[int] = None):
+        d = self.desc
+        for t in (A0, out_h, resid, out_h2):
+            assert t is None or (t.dtype == torch.float16 and t.is_cuda and t.numel() == d.M * self.Cn and t.is_contiguous())
+        d.X, d.W = A0.data_ptr(), self.w.data_ptr()
+        d.bias = self.bias.data_ptr() if self.bias is not None else None
+        d.resid = resid.data_ptr() if resid is not None else None
+        d.out_h = out_h.data_ptr()
+        d.out_h2 = out_h2.data_ptr() if out_h2 is not None else None
+        if stream is None:
+            stream = torch.cuda.current_stream().cuda_stream
+        _lib.check(_lib.lib().advh_conv_taps_f16(C.byref(d), self.Cn, stream), "advh_conv_taps_f16")
+
+
+def taps_supported(src: Map1D, dst: Map1D, weight: torch.Tensor, dilation: int) -> bool:
+    Cout, Cin, k = weight.shape
+    return (Cout == Cin and Cin in (32, 64) and src.C == Cin and dst.C == Cout and src.halo == dst.halo and k <= 16
+            and taps_tile(Cin, k, (k - 1) * dilation) > 0)
+
+
+def plan_conv1d_taps(src: Map1D, dst: Map1D, weight: torch.Tensor, bias: Optional[torch.Tensor], *, dilation: int = 1,
+                     act: str = "none", slope: float = 0.0, slope2: float = 0.0, device=None) -> TapsPlan:
+    """Same layer as :func:`plan_conv1d_same`, on the weights-in-LDS kernel (C_in = C_out in {32, 64})."""
+    Cout, Cin, k = weight.shape
+    pad = (k - 1) * dilation // 2
+    assert taps_supported(src, dst, weight, dilation) and src.halo >= pad and (src.B, src.T) == (dst.B, dst.T)
+    toff = [j * dilation - pad for j in range(k)]
+    return TapsPlan(M=dst.B * dst.P, Cn=Cin, w_taps=weight.permute(2, 0, 1).float(), toff=toff, Hg=1, Wg=dst.P,
+                    window=(0, 1, dst.halo, dst.halo + dst.T), bias=bias, act=act, slope=slope, slope2=slope2,
+                    device=device)
+
+
+def replay_taps_on_cpu(plan: TapsPlan, X: torch.Tensor, resid: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Execute a taps descriptor in numpy as the kernel addresses memory (rows clamped to the map).  Test aid."""
+    d, Cn = plan.desc, plan.Cn
+    x = X.reshape(-1, Cn).float().numpy()
+    W = plan.w.float().cpu().numpy()
+    out = np.zeros((d.M, Cn), dtype=np.float32)
+    rows = np.arange(d.M)
+    w_, h_ = rows % d.Wg, (rows // d.Wg) % d.Hg
+    ok = (h_ >= d.h0) & (h_ < d.h1) & (w_ >= d.w0) & (w_ < d.w1)
+    for t in range(d.ntap):
+        src = np.clip(rows + d.toff[t], 0, d.M - 1)
+        out += x[src] @ W[t].T
+    if plan.bias is not None:
+        out += plan.bias.cpu().numpy()[None]
+    if d.act == 2:
+        out = np.where(out > 0, out, d.slope * out)
+    if resid is not None:
+        out += resid.reshape(-1, Cn).float().numpy()
+    out[~ok] = 0.0
+    return torch.from_numpy(out)
+
+
 def plan_convT1d(src: Map1D, dst: Map1D, weight: torch.Tensor, bias: torch.Tensor, *, stride: int,
                  slope2: float = 0.0, device=None) -> GemmPlan:
     """nn.ConvTranspose1d(k = 2*stride, stride, padding = stride/2) -- the HiFi-GAN upsamplers -- by phase

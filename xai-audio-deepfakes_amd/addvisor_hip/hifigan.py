@@ -19,9 +19,11 @@ HALO = 32          # >= the largest "same" padding: (11 - 1) * 5 / 2 = 25
 
 
 class HipHifigan:
-    def __init__(self, cfg: HifiganConfig, sd: Dict[str, torch.Tensor], device):
+    def __init__(self, cfg: HifiganConfig, sd: Dict[str, torch.Tensor], device, line_tile: bool = True):
+        """``line_tile``: run the 32- / 64-channel ResBlock convolutions on the weights-in-LDS kernel
+        (``advh_conv_taps_f16``) instead of the implicit GEMM."""
         _lib.init()
-        self.cfg, self.dev = cfg, device
+        self.cfg, self.dev, self.line_tile = cfg, device, line_tile
         self.sd = {k: v.detach().float() for k, v in sd.items()}
         ch = cfg.upsample_initial_channel
         for _ in cfg.upsample_rates:
@@ -40,6 +42,12 @@ class HipHifigan:
             return self._ws[key]
         cfg, sd, dev = self.cfg, self.sd, self.dev
         M = lambda t, c: G.Map1D(B, t, c, HALO).alloc(dev)
+
+        def conv(src, dst, w, b, **kw):
+            if self.line_tile and G.taps_supported(src, dst, w, kw.get("dilation", 1)):
+                return G.plan_conv1d_taps(src, dst, w, b, device=dev, **kw)
+            return G.plan_conv1d_same(src, dst, w, b, device=dev, **kw)
+
         ch = cfg.upsample_initial_channel
         mel = M(T, cfg.in_channels)
         cur = M(T, ch)                       # lrelu(conv_pre(mel))
@@ -60,13 +68,13 @@ class HipHifigan:
                 cx, clx = x, lx
                 for d in range(nd):
                     last = d == nd - 1
-                    steps.append(("gemm", G.plan_conv1d_same(clx, tmp, sd[p + f"convs1.{d}.weight"], sd[p + f"convs1.{d}.bias"],
-                                                             dilation=cfg.resblock_dilations[d], act="leaky",
-                                                             slope=cfg.leaky_slope, device=dev), clx, None, tmp, None))
+                    steps.append(("gemm", conv(clx, tmp, sd[p + f"convs1.{d}.weight"], sd[p + f"convs1.{d}.bias"],
+                                               dilation=cfg.resblock_dilations[d], act="leaky", slope=cfg.leaky_slope),
+                                  clx, None, tmp, None))
                     ox = outs[j] if last else (pa if d % 2 == 0 else pb)
                     ol = None if last else (la if d % 2 == 0 else lb)
-                    steps.append(("gemm", G.plan_conv1d_same(tmp, ox, sd[p + f"convs2.{d}.weight"], sd[p + f"convs2.{d}.bias"],
-                                                             slope2=cfg.leaky_slope, device=dev), tmp, cx, ox, ol))
+                    steps.append(("gemm", conv(tmp, ox, sd[p + f"convs2.{d}.weight"], sd[p + f"convs2.{d}.bias"],
+                                               slope2=cfg.leaky_slope), tmp, cx, ox, ol))
                     cx, clx = ox, ol
             nxt = M(t2, co)
             slope = cfg.leaky_slope if i < nstage - 1 else 0.01            # F.leaky_relu default before conv_post

@@ -1,0 +1,236 @@
+// LDS line-tile convolution for narrow layers (C = 32 or 64 channels in and out): the HiFi-GAN V1 MRF
+// ResBlock Conv1d layers of the two late stages (k = 3 / 7 / 11, dilation 1 / 3 / 5) -- hifigan.py:106-110, 180 via
+// SpeechBrain's generator -- and any other "same" convolution that is a sum of taps at constant row offsets of a
+// zero-haloed channels-last map (a 3x3 Conv2d on a padded NHWC map is 9 such taps).
+//
+// With 32 / 64 channels the implicit GEMM re-reads the input once per tap through L2 and is bound by the
+// global->LDS path; here a persistent workgroup keeps the WHOLE weight tensor (k*C*C fp16 <= 90 KiB) resident in
+// LDS, streams position tiles through a line buffer (tile + halo rows, loaded once, contiguous in HBM) and feeds
+// the matrix cores from LDS only: HBM traffic = input once + output once.
+// MFMA orientation as in gemm.hip: weights are the A operand (rows = output channels), positions the B operand,
+// so a lane holds 4 consecutive output channels of one position.
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include "addvisor_hip.h"
+#include "common.h"
+
+namespace advh {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define DS_READ128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#define LGKM_WAIT(n) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(n) : "memory")
+
+// 16-byte chunk c of LDS row r is stored at slot c ^ swz(r): conflict-free ds_read_b128 for 16 consecutive rows
+// starting anywhere (enumerated in tests/test_gemm_plan.py)
+template <int C> __device__ __forceinline__ int swz(int r) { return C == 64 ? (r & 7) : ((r >> 1) & 2); }
+
+// MFMA row R = 16 i + 4 g + r of the weight operand carries output channel cout_of(R): the accumulators of the tile
+// pair (2q, 2q+1) of one lane are then the 8 CONSECUTIVE channels 32 q + 8 g .. + 7 -> 16-byte stores, 64 contiguous
+// bytes per position and store instruction (the row permutation is applied on the source side of the weight DMA).
+__device__ __forceinline__ int cout_of(int R) { return ((R >> 5) << 5) + (((R >> 2) & 3) << 3) + (((R >> 4) & 1) << 2) + (R & 3); }
+
+// NJ = 16-position column tiles per wavefront; a workgroup (4 wavefronts) owns TT = 64 * NJ positions per tile.
+// The line buffer is double-buffered: the DMA of tile i+1 runs under the MFMAs and the stores of tile i.
+template <int C, int NJ>
+__global__ __launch_bounds__(256) void conv_taps_kernel(const advh_taps_desc p) {
+    constexpr int CH = C / 8, CT = C / 16, KS = C / 32, TT = 64 * NJ;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int fr = lane & 15, g = lane >> 4;
+    int lo = 0, hi = 0;
+    for (int t = 0; t < p.ntap; ++t) { lo = min(lo, p.toff[t]); hi = max(hi, p.toff[t]); }
+    const int SR = TT + hi - lo;                                   // line-buffer rows
+    const int SRC = (SR * CH + 63) & ~63;                          // chunks per buffer (whole wave loads)
+    char* Wl = lds;                                                // [ntap*C][C] halfs
+    char* Xl = lds + (size_t)p.ntap * C * C * 2;                   // 2 x [SR][C] halfs
+
+    // ---- weights: once per workgroup
+    const _Float16* Wg = (const _Float16*)p.W;
+    for (int i = tid; i < p.ntap * C * CH; i += 256) {             // i = lds chunk index (wave-linear)
+        int row = i / CH, pos = i % CH;
+        const _Float16* src = Wg + ((long)(row / C) * C + cout_of(row % C)) * C + ((pos ^ swz<C>(row)) * 8);
+        __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src), LDS_PTR(Wl + (size_t)(i - lane) * 16), 16, 0, 0);
+    }
+    const _Float16* X = (const _Float16*)p.X;
+    const int ntiles = (p.M + TT - 1) / TT;
+    // rows p0+lo .. p0+TT+hi, clamped: rows outside the map only ever feed halo outputs (written as zeros)
+    auto load_lines = [&](int tile, int buf) {
+        const long p0 = (long)tile * TT + lo;
+        char* dst = Xl + (size_t)buf * SRC * 16;
+        for (int i = tid; i < SRC; i += 256) {
+            int row = i / CH, pos = i % CH;
+            long r = p0 + row;
+            r = r < 0 ? 0 : (r >= p.M ? p.M - 1 : r);
+            const _Float16* src = X + r * C + ((pos ^ swz<C>(row)) * 8);
+            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src), LDS_PTR(dst + (size_t)(i - lane) * 16), 16, 0, 0);
+        }
+    };
+    float4 bias[CT];                                               // bias[2q + e] = channels 32 q + 8 g + 4 e .. + 3
+#pragma unroll
+    for (int i = 0; i < CT; ++i)
+        bias[i] = p.bias ? *(const float4*)(p.bias + (i >> 1) * 32 + g * 8 + (i & 1) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+
+    const int NS = p.ntap * KS;                                    // 32-deep k steps
+    const unsigned lds0 = (unsigned)(unsigned long)LDS_PTR(lds);
+    int toffv = 0;                                                 // lane t holds toff[t]: v_readlane in the loop, no memory op
+#pragma unroll
+    for (int t = 0; t < 16; ++t) toffv = (lane == t) ? p.toff[t] : toffv;
+    int buf = 0;
+    if ((int)blockIdx.x < ntiles) load_lines(blockIdx.x, 0);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, buf ^= 1) {
+        const long p0 = (long)tile * TT;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                           // buffer `buf` landed; everyone left buffer buf^1
+        if (tile + (int)gridDim.x < ntiles) load_lines(tile + gridDim.x, buf ^ 1);
+        const unsigned xl = lds0 + (unsigned)p.ntap * (C * C * 2) + (unsigned)buf * SRC * 16;
+
+        f32x4 acc[CT][NJ];
+#pragma unroll
+        for (int i = 0; i < CT; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // Fragment pipeline: the CT + NJ ds_reads of k-step s+1 are issued one per MFMA gap of step s.  The reads are
+        // inline asm (hipcc would wait lgkmcnt(0) at the first use AND after the scalar tap-offset lookup), so each
+        // step starts with the one wait that covers exactly the reads of the previous gap sequence.
+        auto issue = [&](int s, int m, f16x8 (&wf)[CT], f16x8 (&xf)[NJ], unsigned wa_, unsigned xa_) {
+            (void)s;
+#pragma unroll
+            for (int i = 0; i < CT; ++i)
+                if (m == i) DS_READ128(wf[i], wa_, i * 16 * C * 2);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+                if (m == CT + j) DS_READ128(xf[j], xa_, j * 16 * C * 2);
+        };
+        auto addr = [&](int s, unsigned& wa_, unsigned& xa_) {
+            const int t = s / KS, c = (s % KS) * 4 + g;
+            wa_ = lds0 + (unsigned)t * (C * C * 2) + (fr * CH + (c ^ swz<C>(fr))) * 16;
+            const int row = wv * (16 * NJ) + fr + __builtin_amdgcn_readlane(toffv, t) - lo;
+            xa_ = xl + (row * CH + (c ^ swz<C>(row))) * 16;
+        };
+        auto step = [&](int sn, const f16x8 (&wc)[CT], const f16x8 (&xc)[NJ], f16x8 (&wn)[CT], f16x8 (&xn)[NJ]) {
+            unsigned wa_, xa_;
+            addr(sn, wa_, xa_);
+            LGKM_WAIT(0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < CT * NJ; ++m) {
+                const int i = m / NJ, j = m % NJ;
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wc[i], xc[j], acc[i][j], 0, 0, 0);
+                if (m < CT + NJ) issue(sn, m, wn, xn, wa_, xa_);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        f16x8 wa[CT], xa[NJ], wb[CT], xb[NJ];
+        {
+            unsigned wa_, xa_;
+            addr(0, wa_, xa_);
+#pragma unroll
+            for (int m = 0; m < CT + NJ; ++m) issue(0, m, wa, xa, wa_, xa_);
+        }
+        for (int s = 0; s < NS; s += 2) {
+            step(min(s + 1, NS - 1), wa, xa, wb, xb);
+            if (s + 1 < NS) step(min(s + 2, NS - 1), wb, xb, wa, xa);
+        }
+        LGKM_WAIT(0);                                              // the last (redundant) prefetch must land before its registers are reused
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- epilogue: bias, LeakyReLU, residual, fp16 stores (and the pre-activated copy)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const long pos = p0 + wv * (16 * NJ) + j * 16 + fr;
+            if (pos >= p.M) continue;
+            unsigned w = (unsigned)(pos % p.Wg), tq = (unsigned)(pos / p.Wg);
+            unsigned h = tq % (unsigned)p.Hg;
+            const bool ok = (int)h >= p.h0 && (int)h < p.h1 && (int)w >= p.w0 && (int)w < p.w1;
+#pragma unroll
+            for (int q = 0; q < CT / 2; ++q) {
+                const long o = pos * C + q * 32 + g * 8;
+                float v[8];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { v[r] = acc[2 * q][j][r]; v[4 + r] = acc[2 * q + 1][j][r]; }
+                if (ok) {
+                    v[0] += bias[2 * q].x; v[1] += bias[2 * q].y; v[2] += bias[2 * q].z; v[3] += bias[2 * q].w;
+                    v[4] += bias[2 * q + 1].x; v[5] += bias[2 * q + 1].y; v[6] += bias[2 * q + 1].z; v[7] += bias[2 * q + 1].w;
+                    if (p.act == ADVH_ACT_LEAKY) {
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) v[r] = v[r] > 0.f ? v[r] : p.slope * v[r];
+                    }
+                    if (p.resid) {
+                        f16x8 rr = *(const f16x8*)((const _Float16*)p.resid + o);
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) v[r] += (float)rr[r];
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) v[r] = 0.f;
+                }
+                f16x8 hv;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) hv[r] = (_Float16)v[r];
+                *(f16x8*)((_Float16*)p.out_h + o) = hv;
+                if (p.out_h2) {
+                    f16x8 h2;
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) h2[r] = (_Float16)(v[r] > 0.f ? v[r] : p.slope2 * v[r]);
+                    *(f16x8*)((_Float16*)p.out_h2 + o) = h2;
+                }
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+static int taps_span(const advh_taps_desc* d) {
+    int lo = 0, hi = 0;
+    for (int t = 0; t < d->ntap; ++t) { lo = d->toff[t] < lo ? d->toff[t] : lo; hi = d->toff[t] > hi ? d->toff[t] : hi; }
+    return hi - lo;
+}
+
+static int taps_lds(int C, int ntap, int span, int nj) {
+    return ntap * C * C * 2 + 2 * (((64 * nj + span) * (C / 8) + 63) / 64 * 64) * 16;
+}
+
+}  // namespace advh
+
+using namespace advh;
+
+// column tiles per wavefront: the widest tile whose weights + two line buffers fit the 160 KiB of LDS
+extern "C" int advh_conv_taps_tile(int C, int ntap, int span) {
+    for (int nj = 4; nj >= 2; --nj)
+        if (taps_lds(C, ntap, span, nj) <= 160 * 1024) return 64 * nj;
+    return 0;
+}
+
+extern "C" int advh_conv_taps_lds_bytes(int C, int ntap, int span) {
+    const int tt = advh_conv_taps_tile(C, ntap, span);
+    return tt ? taps_lds(C, ntap, span, tt / 64) : -1;
+}
+
+extern "C" int advh_conv_taps_f16(const advh_taps_desc* d, int C, advh_stream_t stream) {
+    if (!d || !d->X || !d->W || !d->out_h || d->M <= 0 || d->ntap <= 0 || d->ntap > 16 || d->Hg <= 0 || d->Wg <= 0) return ADVH_EINVAL;
+    if (C != 32 && C != 64) return ADVH_EUNSUPPORTED;
+    if (d->act != ADVH_ACT_NONE && d->act != ADVH_ACT_LEAKY) return ADVH_EINVAL;
+    const int span = taps_span(d);
+    const int tt = advh_conv_taps_tile(C, d->ntap, span);
+    if (!tt) return ADVH_EUNSUPPORTED;
+    const int nj = tt / 64, lds = taps_lds(C, d->ntap, span, nj);
+    typedef void (*kern_t)(const advh_taps_desc);
+    static const kern_t kerns[2][3] = {{conv_taps_kernel<32, 2>, conv_taps_kernel<32, 3>, conv_taps_kernel<32, 4>},
+                                       {conv_taps_kernel<64, 2>, conv_taps_kernel<64, 3>, conv_taps_kernel<64, 4>}};
+    static bool attr[2][3] = {{false, false, false}, {false, false, false}};
+    const int ci = C == 64, ji = nj - 2;
+    if (!attr[ci][ji]) {
+        if (hipFuncSetAttribute((const void*)kerns[ci][ji], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return ADVH_ELAUNCH;
+        attr[ci][ji] = true;
+    }
+    const int ntiles = (d->M + tt - 1) / tt;
+    const int per_cu = lds <= 40 * 1024 ? 4 : (lds <= 53 * 1024 ? 3 : (lds <= 80 * 1024 ? 2 : 1));
+    int grid = 256 * per_cu;
+    if (grid > ntiles) grid = ntiles;
+    hipLaunchKernelGGL(kerns[ci][ji], dim3(grid), dim3(256), lds, (hipStream_t)stream, *d);
+    return ADVH_LAUNCH_CHECK();
+}
