@@ -133,6 +133,11 @@ typedef struct advh_gemm_desc {
        layer's pre-activation.                                                                          */
     void* out_pre;
     const void* dact_src;
+    /* wide = 1: the rows of W are packed permuted inside every 32-row block -- packed row R holds output channel
+       32 (R>>5) + 8 ((R>>2)&3) + 4 ((R>>4)&1) + (R&3) -- so that a lane's accumulators are 8 consecutive channels and
+       the epilogue moves 16 bytes of fp16 per lane.  Requires N, n_div, o_c0 and every o_s* stride % 8 == 0
+       (checked).  wide = 0: packed row R is channel R.                                                     */
+    int32_t wide;
 } advh_gemm_desc;
 
 int advh_gemm_f16(const advh_gemm_desc* desc, int tile, advh_stream_t stream);

@@ -8,6 +8,7 @@ the CPU (tests/test_gemm_plan.py) by replaying the descriptor in numpy.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
 
@@ -18,6 +19,13 @@ from . import _lib
 
 BK = 64
 ACT = {"none": 0, "gelu": 1, "leaky": 2}
+WIDE_EPILOGUE = os.environ.get("ADDVISOR_GEMM_WIDE", "1") != "0"      # A/B switch for the 16-byte epilogue
+
+
+def packed_row_channel(rows: int) -> np.ndarray:
+    """Output channel carried by packed weight row R in the wide layout (``advh_gemm_desc.wide``)."""
+    R = np.arange(rows)
+    return ((R >> 5) << 5) + (((R >> 2) & 3) << 3) + (((R >> 4) & 1) << 2) + (R & 3)
 TILE_AUTO, TILE_128x128, TILE_256x64, TILE_256x32, TILE_256x256, TILE_256x128, TILE_256x128_W4, TILE_128x256_W4, TILE_256x256_RING = 0, 1, 2, 3, 4, 5, 6, 7, 8
 TILE_BN = {TILE_128x128: 128, TILE_256x64: 64, TILE_256x32: 32, TILE_256x256: 256, TILE_256x128: 128, TILE_256x128_W4: 128, TILE_128x256_W4: 256, TILE_256x256_RING: 256}
 TILE_NAMES = {TILE_128x128: "128x128", TILE_256x64: "256x64", TILE_256x32: "256x32", TILE_256x256: "256x256p", TILE_256x128: "256x128p",
@@ -39,7 +47,7 @@ class GemmDesc(C.Structure):
         ("n_div", C.c_int32), ("nz", C.c_int32), ("act", C.c_int32), ("slope", C.c_float),
         ("resid_f32", C.c_int32), ("ktab_identity", C.c_int32),
         ("out_h2", C.c_void_p), ("slope2", C.c_float), ("ph_r", C.c_int32), ("ph_pad", C.c_int32), ("ph_T", C.c_int32),
-        ("out_pre", C.c_void_p), ("dact_src", C.c_void_p),
+        ("out_pre", C.c_void_p), ("dact_src", C.c_void_p), ("wide", C.c_int32),
     ]
 
 
@@ -111,6 +119,9 @@ class GemmPlan:
         does not depend on the batch)."""
         K = 8 * len(ktab)
         Kp = round_up(K, BK)
+        n_div_v = n_div if n_div is not None else round_up(N, 4)
+        # 16-byte epilogue stores need 8 consecutive channels per lane (permuted weight rows) and 8-aligned addressing
+        wide = WIDE_EPILOGUE and N % 8 == 0 and n_div_v % 8 == 0 and all(int(x) % 8 == 0 for x in (*out, o_sNhi, o_sZ))
         tile, BN = pick_tile(N)
         w_rows = round_up(N, 256)        # any tile's BN divides 256: the tile can be re-chosen later (autotune)
         store, ckey = cache if cache is not None else (None, None)
@@ -119,22 +130,28 @@ class GemmPlan:
             w2t = w2() if callable(w2) else w2
             assert w2t.dim() == 3 and w2t.shape[0] == nz and w2t.shape[1] == N and w2t.shape[2] == K, (w2t.shape, nz, N, K)
             wp = torch.zeros((nz, w_rows, Kp), dtype=torch.float16)
-            wp[:, :N, :K] = w2t.to(torch.float16)
+            if wide:
+                src = packed_row_channel(w_rows)
+                keep = src < N
+                wp[:, torch.from_numpy(np.nonzero(keep)[0]), :K] = w2t.to(torch.float16)[:, torch.from_numpy(src[keep])]
+            else:
+                wp[:, :N, :K] = w2t.to(torch.float16)
             wd = wp.to(device) if device is not None else wp
             bd = None
             if bias is not None:
                 assert bias.numel() == nz * N or bias_sZ == 0
                 bd = bias.to(torch.float32).contiguous()
                 bd = bd.to(device) if device is not None else bd
-            hit = (wd, bd)
+            hit = (wd, bd, wide)
             if store is not None:
                 store[ckey] = hit
+        assert hit[2] == wide, "a cached packed weight is shared between plans of different output alignment"
         kt = np.concatenate([ktab, np.full((Kp - K) // 8, ktab[0], dtype=np.int64)]).astype(np.int64)
         assert (kt & 0x7FFFFFFF).max() < 2 ** 31
         self.ktab_host = kt
         self.K, self.Kp, self.tile, self.BN = K, Kp, tile, BN
         self.device = device
-        self.w, self.bias = hit
+        self.w, self.bias = hit[0], hit[1]
         kt32 = torch.from_numpy(kt.astype(np.uint32).view(np.int32).copy())
         self.ktab = kt32.to(device) if device is not None else kt32
         d = GemmDesc()
@@ -148,7 +165,8 @@ class GemmPlan:
         d.bias_sZ = bias_sZ
         d.o_sB, d.o_sH, d.o_sW, d.o_c0 = out
         d.o_sNhi, d.o_sZ = o_sNhi, o_sZ
-        d.n_div = n_div if n_div is not None else round_up(N, 4)
+        d.n_div = n_div_v
+        d.wide = int(wide)
         d.nz = nz
         d.act, d.slope = ACT[act], slope
         d.slope2 = slope2
@@ -342,6 +360,11 @@ def replay_on_cpu(plan: GemmPlan, A0: torch.Tensor, A1: Optional[torch.Tensor], 
     d = plan.desc
     srcs = [A0.reshape(-1).float().numpy(), None if A1 is None else A1.reshape(-1).float().numpy()]
     W = plan.w.float().numpy()
+    if d.wide:                                     # undo the row permutation of the wide packing
+        src = packed_row_channel(W.shape[1])
+        Wl = np.zeros_like(W)
+        Wl[:, src] = W
+        W = Wl
     bias = None if plan.bias is None else plan.bias.numpy().reshape(-1)
     out = np.full(out_numel, np.nan, dtype=np.float32) if out_init is None else out_init.reshape(-1).float().numpy().copy()
     kt = plan.ktab_host

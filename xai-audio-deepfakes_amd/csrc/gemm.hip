@@ -65,10 +65,68 @@ struct RowDecomp {
     }
 };
 
-// Epilogue shared by the GEMM kernels: lane (fr = lane & 15, fq = lane >> 4) holds, per (ni, mi), output
-// channels n .. n+3 of row m (W is the MFMA A operand).  bias + activation + residual + fp16 / fp32 stores.
+// Epilogue shared by the GEMM kernels: lane (fr = lane & 15, fq = lane >> 4) holds, per (ni, mi), the 4 values of
+// MFMA rows 16 ni + 4 fq .. + 3 of the weight operand for row m.  bias + activation + residual + fp16 / fp32 stores.
+// Narrow form (p.wide == 0): weight row R is output channel R, so these are channels n .. n+3 (8-byte fp16 stores).
+// Wide form (p.wide == 1): the host packed the weight rows permuted inside every 32-row block (R -> channel
+// 32 (R>>5) + 8 ((R>>2)&3) + 4 ((R>>4)&1) + (R&3)), so the tile pair (2q, 2q+1) of a lane is 8 CONSECUTIVE channels:
+// 16-byte fp16 / 32-byte fp32 accesses, 64 / 128 contiguous bytes per row and instruction.
+template <int VW>
+__device__ __forceinline__ void epilogue_store(const advh_gemm_desc& p, float (&v)[VW], bool ok, const float* bias, int n, long o) {
+    typedef _Float16 hvec __attribute__((ext_vector_type(VW)));
+    if (ok) {
+        if (bias) {
+#pragma unroll
+            for (int c = 0; c < VW; c += 4) { float4 bb = *(const float4*)(bias + n + c); v[c] += bb.x; v[c + 1] += bb.y; v[c + 2] += bb.z; v[c + 3] += bb.w; }
+        }
+        if (p.out_pre) {
+            hvec pv;
+#pragma unroll
+            for (int r = 0; r < VW; ++r) pv[r] = (_Float16)v[r];
+            *(hvec*)((_Float16*)p.out_pre + o) = pv;
+        }
+#pragma unroll
+        for (int r = 0; r < VW; ++r) v[r] = apply_act(v[r], p.act, p.slope);
+        if (p.dact_src) {
+            hvec zz = *(const hvec*)((const _Float16*)p.dact_src + o);
+#pragma unroll
+            for (int r = 0; r < VW; ++r) v[r] *= gelu_grad((float)zz[r]);
+        }
+        if (p.resid) {
+            if (p.resid_f32) {
+#pragma unroll
+                for (int c = 0; c < VW; c += 4) { float4 rr = *(const float4*)((const float*)p.resid + o + c); v[c] += rr.x; v[c + 1] += rr.y; v[c + 2] += rr.z; v[c + 3] += rr.w; }
+            } else {
+                hvec rr = *(const hvec*)((const _Float16*)p.resid + o);
+#pragma unroll
+                for (int r = 0; r < VW; ++r) v[r] += (float)rr[r];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < VW; ++r) v[r] = 0.f;
+    }
+    if (p.out_f) {
+#pragma unroll
+        for (int c = 0; c < VW; c += 4) *(float4*)((float*)p.out_f + o + c) = make_float4(v[c], v[c + 1], v[c + 2], v[c + 3]);
+    }
+    if (p.out_h) {
+        hvec hv;
+#pragma unroll
+        for (int r = 0; r < VW; ++r) hv[r] = (_Float16)v[r];
+        *(hvec*)((_Float16*)p.out_h + o) = hv;
+    }
+    if (p.out_h2) {
+        hvec hv;
+#pragma unroll
+        for (int r = 0; r < VW; ++r) hv[r] = (_Float16)(v[r] > 0.f ? v[r] : p.slope2 * v[r]);
+        *(hvec*)((_Float16*)p.out_h2 + o) = hv;
+    }
+}
+
 template <int MI, int NI>
 __device__ __forceinline__ void gemm_epilogue(const advh_gemm_desc& p, f32x4 (&acc)[NI][MI], int mw0, int nw0, int fr, int fq, int z) {
+    static_assert(NI % 2 == 0, "the wide epilogue pairs n-tiles");
     const float* bias = p.bias ? p.bias + (long)p.bias_sZ * z : nullptr;
     const RowDecomp rd(p.Wg, p.Hg);
 #pragma unroll
@@ -80,59 +138,40 @@ __device__ __forceinline__ void gemm_epilogue(const advh_gemm_desc& p, f32x4 (&a
         bool ok = (int)h >= p.h0 && (int)h < p.h1 && (int)w >= p.w0 && (int)w < p.w1;
         if (!ok && !p.halo_zero) continue;
         long orow = (long)b * p.o_sB + (long)h * p.o_sH + (long)w * p.o_sW + p.o_c0 + p.o_sZ * z;
+        if (p.wide) {
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-            int n = nw0 + ni * 16 + fq * 4;
-            if (n >= p.N) continue;
-            if (p.ph_r > 0) {                              // transposed-conv phase window (column-dependent validity)
-                int to = (int)w * p.ph_r + n / p.n_div - p.ph_pad;
-                if (to < 0 || to >= p.ph_T) continue;
-            }
-            long o = orow + (long)(n / p.n_div) * p.o_sNhi + (n % p.n_div);
-            f32x4 v = acc[ni][mi];
-            if (ok) {
-                if (bias) { float4 bb = *(const float4*)(bias + n); v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w; }
-                if (p.out_pre) {
-                    f16x4 pv = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
-                    *(f16x4*)((_Float16*)p.out_pre + o) = pv;
+            for (int q = 0; q < NI / 2; ++q) {
+                int n = nw0 + q * 32 + fq * 8;
+                if (n >= p.N) continue;
+                if (p.ph_r > 0) {
+                    int to = (int)w * p.ph_r + n / p.n_div - p.ph_pad;
+                    if (to < 0 || to >= p.ph_T) continue;
                 }
+                long o = orow + (long)(n / p.n_div) * p.o_sNhi + (n % p.n_div);
+                float v[8];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], p.act, p.slope);
-                if (p.dact_src) {
-                    f16x4 zz = *(const f16x4*)((const _Float16*)p.dact_src + o);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] *= gelu_grad((float)zz[r]);
-                }
-                if (p.resid) {
-                    if (p.resid_f32) {
-                        float4 rr = *(const float4*)((const float*)p.resid + o);
-                        v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
-                    } else {
-                        f16x4 rr = *(const f16x4*)((const _Float16*)p.resid + o);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
-                    }
-                }
-            } else {
-                v = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int r = 0; r < 4; ++r) { v[r] = acc[2 * q][mi][r]; v[4 + r] = acc[2 * q + 1][mi][r]; }
+                epilogue_store<8>(p, v, ok, bias, n, o);
             }
-            if (p.out_f) *(float4*)((float*)p.out_f + o) = make_float4(v[0], v[1], v[2], v[3]);
-            if (p.out_h) {
-                f16x4 hv = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
-                *(f16x4*)((_Float16*)p.out_h + o) = hv;
-            }
-            if (p.out_h2) {
-                f16x4 hv;
+        } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) hv[r] = (_Float16)(v[r] > 0.f ? v[r] : p.slope2 * v[r]);
-                *(f16x4*)((_Float16*)p.out_h2 + o) = hv;
+            for (int ni = 0; ni < NI; ++ni) {
+                int n = nw0 + ni * 16 + fq * 4;
+                if (n >= p.N) continue;
+                if (p.ph_r > 0) {                              // transposed-conv phase window (column-dependent validity)
+                    int to = (int)w * p.ph_r + n / p.n_div - p.ph_pad;
+                    if (to < 0 || to >= p.ph_T) continue;
+                }
+                long o = orow + (long)(n / p.n_div) * p.o_sNhi + (n % p.n_div);
+                float v[4] = {acc[ni][mi][0], acc[ni][mi][1], acc[ni][mi][2], acc[ni][mi][3]};
+                epilogue_store<4>(p, v, ok, bias, n, o);
             }
         }
     }
 }
 
 template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void gemm_f16_kernel(const advh_gemm_desc p) {
+__global__ __launch_bounds__(256, (BM * BN <= 128 * 128 ? 3 : 1)) void gemm_f16_kernel(const advh_gemm_desc p) {
     constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 16, NI = TN / 16;
     constexpr int NA = BM / 32, NB = BN / 32;      // 16-byte chunks per thread per K-step
     static_assert(WM * WN == 4 && NB >= 1, "4 wavefronts");
