@@ -11,7 +11,7 @@ batches (utterances shard with no data-path collective, "weak" scaling); the onl
 fixed-order gather of the per-clip probabilities for the LMAC metrics, done once inside the timed
 region.  Rank 0 prints ONE JSON line.
 
-`roofline` is for the dominant kernel (the 128x128 implicit-GEMM tile, csrc/gemm.hip): algorithmic
+`roofline` is for the dominant kernel (the implicit-GEMM tile with the largest total time, csrc/gemm.hip): algorithmic
 FLOPs of its launches / their device time, measured with HIP events recorded on the launch stream
 inside the timed steps.  `cpu_baseline` times the CPU oracle (plain torch, the reference arithmetic)
 on a bounded sample of the same workload on this host's cores (rank 0, N = 1 only).
@@ -118,7 +118,8 @@ def main():
 
     n_expl = world * B * args.steps
     value = n_expl / elapsed
-    gemm_ms, gemm_flops, gemm_n = G.PROFILE.summary()
+    gemm_ms, gemm_flops, gemm_n = G.PROFILE.summary()                      # the tile with the largest total time
+    gemm_kernel = G.TILE_KERNELS.get(getattr(G.PROFILE, "tile", None), "gemm_f16_kernel")
     achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else None
     flops_step = pipe.flops(B)
 
@@ -131,7 +132,7 @@ def main():
     if os.path.exists(tpath) and not args.tune:
         with open(tpath) as fh:
             for k, v in json.load(fh).items():
-                if "gemm_f16_kernel<128, 128" in k:
+                if gemm_kernel in k:
                     traffic = round(v["hbm_bytes_per_launch"])
     if rank == 0:
         line = {
@@ -147,7 +148,7 @@ def main():
                        "gflop_per_explanation": round(flops_step / B / 1e9, 1)},
             "lmac": {k: round(v, 6) for k, v in metrics.items()},
             "pipeline_tflops": round(flops_step * args.steps * world / elapsed / 1e12, 1),
-            "roofline": {"kernel": "gemm_f16_kernel<128,128,2,2>" + (" (+ tuned 256-wide tiles)" if args.tune else ""), "bound": "mfma",
+            "roofline": {"kernel": gemm_kernel + (" (tuned tile choice)" if args.tune else ""), "bound": "mfma",
                          "achieved": None if achieved is None else round(achieved, 1), "peak": MFMA_F16_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": None if achieved is None else round(achieved / MFMA_F16_PEAK_TFLOPS, 4),
                          "traffic": traffic, "traffic_source": "profiles/r01_gemm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "

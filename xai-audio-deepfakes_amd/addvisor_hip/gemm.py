@@ -27,9 +27,16 @@ def packed_row_channel(rows: int) -> np.ndarray:
     R = np.arange(rows)
     return ((R >> 5) << 5) + (((R >> 2) & 3) << 3) + (((R >> 4) & 1) << 2) + (R & 3)
 TILE_AUTO, TILE_128x128, TILE_256x64, TILE_256x32, TILE_256x256, TILE_256x128, TILE_256x128_W4, TILE_128x256_W4, TILE_256x256_RING = 0, 1, 2, 3, 4, 5, 6, 7, 8
-TILE_BN = {TILE_128x128: 128, TILE_256x64: 64, TILE_256x32: 32, TILE_256x256: 256, TILE_256x128: 128, TILE_256x128_W4: 128, TILE_128x256_W4: 256, TILE_256x256_RING: 256}
+TILE_256x128_W8, TILE_128x256_W8 = 9, 10
+TILE_BN = {TILE_128x128: 128, TILE_256x64: 64, TILE_256x32: 32, TILE_256x256: 256, TILE_256x128: 128, TILE_256x128_W4: 128, TILE_128x256_W4: 256, TILE_256x256_RING: 256,
+           TILE_256x128_W8: 128, TILE_128x256_W8: 256}
 TILE_NAMES = {TILE_128x128: "128x128", TILE_256x64: "256x64", TILE_256x32: "256x32", TILE_256x256: "256x256p", TILE_256x128: "256x128p",
-              TILE_256x128_W4: "256x128w4", TILE_128x256_W4: "128x256w4", TILE_256x256_RING: "256x256r"}
+              TILE_256x128_W4: "256x128w4", TILE_128x256_W4: "128x256w4", TILE_256x256_RING: "256x256r",
+              TILE_256x128_W8: "256x128w8", TILE_128x256_W8: "128x256w8"}
+# device symbol (as rocprofv3 prints it) of the kernels the live profile covers
+TILE_KERNELS = {TILE_128x128: "gemm_f16_kernel<128, 128, 2, 2, 3>", TILE_128x256_W8: "gemm_f16_kernel<128, 256, 2, 4, 3>",
+                TILE_256x128_W8: "gemm_f16_kernel<256, 128, 4, 2, 3>", TILE_256x256: "gemm_f16_pipe_kernel<256, 256, 2, 4, 2>",
+                TILE_256x128: "gemm_f16_pipe_kernel<256, 128, 4, 2, 3>"}
 
 
 class GemmDesc(C.Structure):
@@ -61,9 +68,18 @@ class _Profile:
     def reset(self, enabled: bool):
         self.enabled, self.events = enabled, []
 
-    def summary(self):
-        ms = sum(a.elapsed_time(b) for a, b, _ in self.events)
-        return ms, sum(f for _, _, f in self.events), len(self.events)
+    def summary(self, tile=None):
+        """(ms, flops, launches) of ``tile``; default: the tile with the largest total time."""
+        per = {}
+        for a, b, f, t in self.events:
+            r = per.setdefault(t, [0.0, 0.0, 0])
+            r[0] += a.elapsed_time(b); r[1] += f; r[2] += 1
+        if not per:
+            return 0.0, 0.0, 0
+        if tile is None:
+            tile = max(per, key=lambda t: per[t][0])
+        self.tile = tile
+        return tuple(per.get(tile, (0.0, 0.0, 0)))
 
 
 PROFILE = _Profile()
@@ -84,13 +100,19 @@ def round_up(x: int, m: int) -> int:
     return (x + m - 1) // m * m
 
 
-def pick_tile(N: int) -> Tuple[int, int]:
-    """(tile id, BN) the AUTO rule of advh_gemm_f16 picks."""
-    if N > 64:
-        return TILE_128x128, 128
-    if N > 32:
+def pick_tile(N: int, M: int = 0) -> Tuple[int, int]:
+    """(tile id, BN) the AUTO rule of advh_gemm_f16 picks (same rule as csrc/gemm.hip): the 512-thread 128x256 /
+    256x128 tiles (25 % less global->LDS traffic per flop) once the launch has enough tiles to fill every CU with two
+    of those workgroups several times over; the 128x128 tile otherwise."""
+    if N <= 32:
+        return TILE_256x32, 32
+    if N <= 64:
         return TILE_256x64, 64
-    return TILE_256x32, 32
+    if N <= 128:
+        return (TILE_256x128_W8, 128) if M >= 256 * 2048 else (TILE_128x128, 128)
+    if round_up(N, 256) == round_up(N, 128) and ((M + 127) // 128) * (round_up(N, 256) // 256) >= 1536:
+        return TILE_128x256_W8, 256
+    return TILE_128x128, 128
 
 
 @dataclass
@@ -122,7 +144,7 @@ class GemmPlan:
         n_div_v = n_div if n_div is not None else round_up(N, 4)
         # 16-byte epilogue stores need 8 consecutive channels per lane (permuted weight rows) and 8-aligned addressing
         wide = WIDE_EPILOGUE and N % 8 == 0 and n_div_v % 8 == 0 and all(int(x) % 8 == 0 for x in (*out, o_sNhi, o_sZ))
-        tile, BN = pick_tile(N)
+        tile, BN = pick_tile(N, M)
         w_rows = round_up(N, 256)        # any tile's BN divides 256: the tile can be re-chosen later (autotune)
         store, ckey = cache if cache is not None else (None, None)
         hit = store.get(ckey) if store is not None else None
@@ -207,18 +229,18 @@ class GemmPlan:
             stream = torch.cuda.current_stream().cuda_stream
         if TUNER.active and not getattr(self, "_tuned", False):
             self._tune(d, stream)
-        prof = PROFILE.enabled and self.tile in (TILE_128x128, TILE_256x256, TILE_256x128)
+        prof = PROFILE.enabled and self.tile not in (TILE_256x64, TILE_256x32)
         if prof:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
         _lib.check(_lib.lib().advh_gemm_f16(C.byref(d), self.tile, stream), "advh_gemm_f16")
         if prof:
             e1.record()
-            PROFILE.events.append((e0, e1, self.flops))
+            PROFILE.events.append((e0, e1, self.flops, self.tile))
 
 
 def _tune(self, d, stream):
-    cands = [TILE_128x128, TILE_256x256, TILE_256x128] if self.desc.N > 64 else [self.tile]
+    cands = [TILE_128x128, TILE_128x256_W8, TILE_256x128_W8, TILE_256x256] if self.desc.N > 64 else [self.tile]
     best, best_ms = self.tile, None
     if len(cands) > 1:
         for t in cands:

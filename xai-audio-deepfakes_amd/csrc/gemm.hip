@@ -170,11 +170,15 @@ __device__ __forceinline__ void gemm_epilogue(const advh_gemm_desc& p, f32x4 (&a
     }
 }
 
-template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256, (BM * BN <= 128 * 128 ? 3 : 1)) void gemm_f16_kernel(const advh_gemm_desc p) {
+// WPE = wavefronts per SIMD the register allocation must allow (amdgpu-waves-per-eu through __launch_bounds__):
+// the single-buffered loop below hides the global->LDS latency with OTHER workgroups of the CU, so occupancy is
+// the lever (4 wavefronts per SIMD = 126 VGPRs for the 64 x 64 wave tile, no spills).
+template <int BM, int BN, int WM, int WN, int WPE>
+__global__ __launch_bounds__(64 * WM * WN, WPE) void gemm_f16_kernel(const advh_gemm_desc p) {
     constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 16, NI = TN / 16;
-    constexpr int NA = BM / 32, NB = BN / 32;      // 16-byte chunks per thread per K-step
-    static_assert(WM * WN == 4 && NB >= 1, "4 wavefronts");
+    constexpr int NT = 64 * WM * WN, RPP = NT / 8;  // threads; tile rows covered by one loader pass
+    constexpr int NA = BM / RPP, NB = BN / RPP;     // 16-byte chunks per thread per K-step
+    static_assert(NA >= 1 && NB >= 1 && BM % RPP == 0 && BN % RPP == 0, "loader passes");
     __shared__ __attribute__((aligned(16))) char smem[(BM + BN) * BK * 2];
     char* ldsA = smem;
     char* ldsB = smem + BM * BK * 2;
@@ -199,7 +203,7 @@ __global__ __launch_bounds__(256, (BM * BN <= 128 * 128 ? 3 : 1)) void gemm_f16_
     const _Float16* Wp = (const _Float16*)p.W + p.w_sZ * z;
 
     // ---- loader setup: this thread's chunk column q and its NA rows' base offsets (chunk units)
-    const int ldrow = tid >> 3;                          // + 32*i
+    const int ldrow = tid >> 3;                          // + RPP*i
     const int q = (tid & 7) ^ (ldrow & 7);               // logical K-chunk this lane fetches (swizzled source)
     // row base of the "safe" row used by invalid rows (halo / M tail): first valid row of item 0
     long safe0 = (long)p.h0 * p.a_sH[0] + (long)p.w0 * p.a_sW[0] + p.a_c0[0];
@@ -208,7 +212,7 @@ __global__ __launch_bounds__(256, (BM * BN <= 128 * 128 ? 3 : 1)) void gemm_f16_
     const RowDecomp rd(p.Wg, p.Hg);
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-        unsigned m = m0 + ldrow + 32 * i;
+        unsigned m = m0 + ldrow + RPP * i;
         unsigned w, h, b;
         rd(m, b, h, w);
         bool ok = m < (unsigned)p.M && (int)h >= p.h0 && (int)h < p.h1 && (int)w >= p.w0 && (int)w < p.w1;
@@ -219,7 +223,7 @@ __global__ __launch_bounds__(256, (BM * BN <= 128 * 128 ? 3 : 1)) void gemm_f16_
     }
     const _Float16* wrow[NB];
 #pragma unroll
-    for (int i = 0; i < NB; ++i) wrow[i] = Wp + (long)(n0 + ldrow + 32 * i) * p.Ktot + q * 8;
+    for (int i = 0; i < NB; ++i) wrow[i] = Wp + (long)(n0 + ldrow + RPP * i) * p.Ktot + q * 8;
 
     // ---- fragment read offsets (bytes) inside a tile: row r, logical chunk c -> (r*8 + (c ^ (r&7)))*16
     const int fr = lane & 15, fq = lane >> 4;
@@ -247,12 +251,12 @@ __global__ __launch_bounds__(256, (BM * BN <= 128 * 128 ? 3 : 1)) void gemm_f16_
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
                 const _Float16* g = base + ((unsigned long)((s1 ? rb1[i] : rb0[i]) + ko)) * 8;
-                __builtin_amdgcn_global_load_lds(GLOBAL_PTR(g), LDS_PTR(ldsA + (wv * 64 + 256 * i) * 16), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(GLOBAL_PTR(g), LDS_PTR(ldsA + (wv * 64 + NT * i) * 16), 16, 0, 0);
             }
 #pragma unroll
             for (int i = 0; i < NB; ++i)
                 __builtin_amdgcn_global_load_lds(GLOBAL_PTR(wrow[i] + kt * BK),
-                                                 LDS_PTR(ldsB + (wv * 64 + 256 * i) * 16), 16, 0, 0);
+                                                 LDS_PTR(ldsB + (wv * 64 + NT * i) * 16), 16, 0, 0);
         }
         if (kt + 1 < nk) kq = p.ktab[(kt + 1) * 8 + q];
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -276,12 +280,12 @@ __global__ __launch_bounds__(256, (BM * BN <= 128 * 128 ? 3 : 1)) void gemm_f16_
     gemm_epilogue<MI, NI>(p, acc, m0 + wm * TM, n0 + wn * TN, fr, fq, z);
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int WPE>
 static int launch(const advh_gemm_desc& d, hipStream_t s) {
     const int tilesM = (d.M + BM - 1) / BM, tilesN = (d.N + BN - 1) / BN;
     if (tilesN * BN > d.w_rows) return ADVH_EINVAL;
     dim3 grid(tilesM * tilesN, 1, d.nz > 0 ? d.nz : 1);
-    hipLaunchKernelGGL((gemm_f16_kernel<BM, BN, WM, WN>), grid, dim3(256), 0, s, d);
+    hipLaunchKernelGGL((gemm_f16_kernel<BM, BN, WM, WN, WPE>), grid, dim3(64 * WM * WN), 0, s, d);
     return ADVH_LAUNCH_CHECK();
 }
 
@@ -597,13 +601,21 @@ extern "C" int advh_gemm_f16(const advh_gemm_desc* d, int tile, advh_stream_t st
         return ADVH_EINVAL;
     if (d->act < ADVH_ACT_NONE || d->act > ADVH_ACT_LEAKY) return ADVH_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    if (tile == ADVH_TILE_AUTO) tile = d->N > 64 ? ADVH_TILE_128x128 : (d->N > 32 ? ADVH_TILE_256x64 : ADVH_TILE_256x32);
+    if (tile == ADVH_TILE_AUTO) {                          // same rule as addvisor_hip/gemm.py pick_tile
+        const int n256 = (d->N + 255) / 256 * 256, n128 = (d->N + 127) / 128 * 128;
+        if (d->N <= 32) tile = ADVH_TILE_256x32;
+        else if (d->N <= 64) tile = ADVH_TILE_256x64;
+        else if (d->N <= 128) tile = d->M >= 256 * 2048 ? ADVH_TILE_256x128_W8 : ADVH_TILE_128x128;
+        else tile = (n256 == n128 && (long)((d->M + 127) / 128) * (n256 / 256) >= 1536) ? ADVH_TILE_128x256_W8 : ADVH_TILE_128x128;
+    }
     switch (tile) {
-        case ADVH_TILE_128x128: return launch<128, 128, 2, 2>(*d, s);
-        case ADVH_TILE_256x64: return launch<256, 64, 4, 1>(*d, s);
-        case ADVH_TILE_256x32: return launch<256, 32, 4, 1>(*d, s);
-        case ADVH_TILE_256x128_W4: return launch<256, 128, 2, 2>(*d, s);
-        case ADVH_TILE_128x256_W4: return launch<128, 256, 2, 2>(*d, s);
+        case ADVH_TILE_128x128: return launch<128, 128, 2, 2, 3>(*d, s);
+        case ADVH_TILE_256x64: return launch<256, 64, 4, 1, 3>(*d, s);
+        case ADVH_TILE_256x32: return launch<256, 32, 4, 1, 3>(*d, s);
+        case ADVH_TILE_256x128_W4: return launch<256, 128, 2, 2, 1>(*d, s);
+        case ADVH_TILE_128x256_W4: return launch<128, 256, 2, 2, 1>(*d, s);
+        case ADVH_TILE_256x128_W8: return launch<256, 128, 4, 2, 3>(*d, s);
+        case ADVH_TILE_128x256_W8: return launch<128, 256, 2, 4, 3>(*d, s);
         case ADVH_TILE_256x256: return launch_pipe<256, 256, 2, 4, 2>(*d, s);
         case ADVH_TILE_256x256_RING: return launch_ring<256, 256, 2, 4>(*d, s);
         case ADVH_TILE_256x128: return launch_pipe<256, 128, 4, 2, 3>(*d, s);
