@@ -101,17 +101,13 @@ def round_up(x: int, m: int) -> int:
 
 
 def pick_tile(N: int, M: int = 0) -> Tuple[int, int]:
-    """(tile id, BN) the AUTO rule of advh_gemm_f16 picks (same rule as csrc/gemm.hip): the 512-thread 128x256 /
-    256x128 tiles (25 % less global->LDS traffic per flop) once the launch has enough tiles to fill every CU with two
-    of those workgroups several times over; the 128x128 tile otherwise."""
+    """(tile id, BN) the AUTO rule of advh_gemm_f16 picks (same rule as csrc/gemm.hip).  The 512-thread 128x256 /
+    256x128 tiles win an isolated-GEMM loop by 10-15 % on the 3B-row shapes but lose ~3 % inside the pipeline
+    (profiles/history): they stay available to the tuner, the rule stays 128x128."""
     if N <= 32:
         return TILE_256x32, 32
     if N <= 64:
         return TILE_256x64, 64
-    if N <= 128:
-        return (TILE_256x128_W8, 128) if M >= 256 * 2048 else (TILE_128x128, 128)
-    if round_up(N, 256) == round_up(N, 128) and ((M + 127) // 128) * (round_up(N, 256) // 256) >= 1536:
-        return TILE_128x256_W8, 256
     return TILE_128x128, 128
 
 

@@ -601,13 +601,8 @@ extern "C" int advh_gemm_f16(const advh_gemm_desc* d, int tile, advh_stream_t st
         return ADVH_EINVAL;
     if (d->act < ADVH_ACT_NONE || d->act > ADVH_ACT_LEAKY) return ADVH_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    if (tile == ADVH_TILE_AUTO) {                          // same rule as addvisor_hip/gemm.py pick_tile
-        const int n256 = (d->N + 255) / 256 * 256, n128 = (d->N + 127) / 128 * 128;
-        if (d->N <= 32) tile = ADVH_TILE_256x32;
-        else if (d->N <= 64) tile = ADVH_TILE_256x64;
-        else if (d->N <= 128) tile = d->M >= 256 * 2048 ? ADVH_TILE_256x128_W8 : ADVH_TILE_128x128;
-        else tile = (n256 == n128 && (long)((d->M + 127) / 128) * (n256 / 256) >= 1536) ? ADVH_TILE_128x256_W8 : ADVH_TILE_128x128;
-    }
+    // same rule as addvisor_hip/gemm.py pick_tile
+    if (tile == ADVH_TILE_AUTO) tile = d->N > 64 ? ADVH_TILE_128x128 : (d->N > 32 ? ADVH_TILE_256x64 : ADVH_TILE_256x32);
     switch (tile) {
         case ADVH_TILE_128x128: return launch<128, 128, 2, 2, 3>(*d, s);
         case ADVH_TILE_256x64: return launch<256, 64, 4, 1, 3>(*d, s);
