@@ -75,6 +75,15 @@ int advh_istft_masked(const float* mag, const float* phase, const float* mask, i
 int advh_istft_c64(const float* spec, float* wave, int64_t wave_stride, int B, int T, int L, int hop, int win,
                    const float* window, advh_stream_t stream);
 
+/* Backward of advh_istft_masked from ONE resynthesised waveform to the mask (LMACLoss backward,
+ * loss_function.py:36-47 / SURVEY.md §8(f) rank 1): g_wave = dL/d wave [B][L] (row stride g_stride), which = 0 for
+ * the mask-in branch (a = m M), 1 for mask-out (a = (1 - m) M); dmask [B][Fm][Tm] is overwritten.  `mask` is only
+ * read in ADVH_MASK_LOG1P mode.  Adjoint of torch.istft: divide by the window envelope, zero-extend, frame with the
+ * synthesis window, rfft, scale by c_k / n_fft.                                                                    */
+int advh_istft_masked_bwd(const float* g_wave, int64_t g_stride, const float* mag, const float* phase, const float* mask,
+                          int Fm, int Tm, int mode, int which, float* dmask, int B, int T, int L, int hop, int win,
+                          const float* window, advh_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Implicit GEMM on the matrix cores (fp16 operands, fp32 accumulate):
  *

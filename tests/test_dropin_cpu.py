@@ -120,3 +120,41 @@ def test_hifigan_module_and_align():
         a1, b1 = hifigan.align_waveforms(ref, deg)
         a2, b2 = hifigan_ref.align_waveforms(ref, deg)
         assert a1.shape == a2.shape == (1, 1, a2.shape[-1]) and torch.equal(a1, a2) and torch.equal(b1, b2)
+
+
+def _ddp_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    import addvisor
+    from oracle import unet_ref
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)                                           # same initial weights on every rank
+    net = addvisor.UNet()
+    net.train()
+    ddp = DDP(net)
+    x = torch.from_numpy(np.random.Generator(np.random.PCG64(100 + rank)).uniform(0, 2, size=(1, 1, 32, 8)).astype(np.float32))
+    mask = ddp(x)                                                  # training forward = autograd graph over the torch modules
+    ref = unet_ref.unet_forward(x, {k: v.detach() for k, v in net.state_dict().items()}, bn_batch=True)
+    ok_fwd = torch.allclose(mask.detach(), ref, atol=1e-5)
+    (mask * (rank + 1)).mean().backward()                         # different local losses; DDP averages the gradients
+    flat = torch.cat([p.grad.reshape(-1) for p in net.parameters()])
+    gathered = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    q.put((rank, ok_fwd and all(torch.equal(g, gathered[0]) for g in gathered) and bool(flat.abs().sum() > 0)))
+    dist.destroy_process_group()
+
+
+def test_unet_training_forward_under_ddp_gloo_world2():
+    """Training step, data-parallel (train_addvisor.py:410-412 hands the model to accelerate = DDP): the drop-in UNet in
+    train() mode is an ordinary autograd module, so the gradient all-reduce (RCCL on the GPUs, gloo here) needs no
+    special casing; its forward equals the oracle's batch-statistics forward."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = [q.get(timeout=180) for _ in procs]
+    [p.join(60) for p in procs]
+    assert all(ok for _, ok in res) and all(p.exitcode == 0 for p in procs)

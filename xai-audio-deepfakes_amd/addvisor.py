@@ -26,7 +26,8 @@ class ConvBlock(nn.Module):
         )
 
     def forward(self, x):
-        raise RuntimeError("ConvBlock is executed as part of UNet.forward on the HIP path")
+        """Only used by the training path of ``UNet.forward`` (autograd through torch's GPU convolutions)."""
+        return self.block(x)
 
 
 class UNet(nn.Module):
@@ -64,10 +65,6 @@ class UNet(nn.Module):
 
     def forward(self, x):
         """``x [B,1,F,T]`` (or ``[B,F,T]``) magnitude, F % 16 == 0 and T % 4 == 0 -> mask, same shape."""
-        if self.training and not self._warned:
-            warnings.warn("UNet is in training mode; the HIP path always uses eval-mode BatchNorm "
-                          "(running statistics), see SURVEY.md D5", stacklevel=2)
-            self._warned = True
         squeeze = x.dim() == 3
         x4 = x[:, None] if squeeze else x
         if x4.dim() != 4 or x4.shape[1] != 1:
@@ -76,8 +73,35 @@ class UNet(nn.Module):
         if Fq % 16 or Tq % 4:
             raise RuntimeError(f"U-Net skip connections need F % 16 == 0 and T % 4 == 0, got {Fq}x{Tq}")
         dev = torch.device("cuda")
+        if self.training and torch.is_grad_enabled():
+            # Training step (train_addvisor.py:364-378): the mask must carry an autograd graph back to the U-Net
+            # parameters.  The decoder's own forward / backward (7 % of the step's FLOPs) runs on torch's GPU
+            # convolutions with batch-statistics BatchNorm, exactly the reference modules; the loss it feeds
+            # (loss_function.LMACLoss: ISTFT x2, frozen embedder x2 and their backward) is the HIP path.
+            # Hand-written dgrad / wgrad kernels for the decoder are SURVEY.md §8(f) rank 1's remainder.
+            self._hip = None                                   # weights change: repack before the next HIP forward
+            mask = self._forward_autograd(x4.to(self.mask_head[0].weight.device, torch.float32))
+            return mask[:, 0] if squeeze else mask
+        if self.training and not self._warned:
+            warnings.warn("UNet is in training mode but gradients are disabled; the HIP path uses eval-mode "
+                          "BatchNorm (running statistics), see SURVEY.md D5", stacklevel=2)
+            self._warned = True
         mask = self._engine(dev).forward(x4[:, 0].to(dev, torch.float32).contiguous(), H=Fq, W=Tq)
         return mask if squeeze else mask[:, None]
+
+    def _forward_autograd(self, x):
+        """addvisor.py:62-84 on the registered torch modules (encoder, dilated bottleneck, transposed-conv
+        upsampling with skip concatenation, 1x1 sigmoid head)."""
+        x1 = self.e1(x)
+        x2 = self.e2(x1)
+        x3 = self.e3(x2)
+        x4 = self.e4(x3)
+        b = self.bottleneck(x4)
+        y4 = self.d4(torch.cat([self.up4(b), x3], 1))
+        y3 = self.d3(torch.cat([self.up3(y4), x2], 1))
+        y2 = self.d2(torch.cat([self.up2(y3), x1], 1))
+        y1 = self.d1(torch.cat([self.up1(y2), x], 1))
+        return self.mask_head(y1)
 
 
 ADDvisor = UNet

@@ -218,8 +218,9 @@ class EmbedderGrad:
             self.cfg.layer_norm_eps if eps is None else eps, remap[0], remap[1], torch.cuda.current_stream().cuda_stream),
             "advh_layernorm_bwd")
 
-    def backward(self, loss_scale: float = 4096.0) -> torch.Tensor:
-        """d logit / d wave for the clips of the last ``forward`` call: ``[B, n_in]`` fp32."""
+    def backward(self, loss_scale: float = 4096.0, seed: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """d logit / d wave for the clips of the last ``forward`` call: ``[B, n_in]`` fp32.  With ``seed [B]``
+        (dL/d logit per clip) the result is dL/d wave instead (vector-Jacobian product: LMACLoss backward)."""
         emb, cfg, lib = self.emb, self.cfg, _lib.lib()
         wave, B, n_in, L = self._last
         w = self._workspace(B, L)
@@ -229,7 +230,10 @@ class EmbedderGrad:
         C, nfe, nl = cfg.conv_dim, len(f["Ls"]), emb.nl
         da, db, d16, t16 = w["da"], w["db"], w["d16"], w["t16"]
         heads = cfg.num_attention_heads
-        w["dlogit"].fill_(loss_scale)
+        if seed is None:
+            w["dlogit"].fill_(loss_scale)
+        else:
+            w["dlogit"].copy_(seed.reshape(-1).to(w["dlogit"].dtype) * loss_scale)
         _lib.check(lib.advh_pool_logreg_bwd(emb.coef.data_ptr(), w["dlogit"].data_ptr(), da.data_ptr(), d16.data_ptr(), B, T, H, st),
                    "advh_pool_logreg_bwd")
         if self._final_ln:

@@ -92,6 +92,36 @@ def istft_masked(mag: torch.Tensor, phase: torch.Tensor, mask: Optional[torch.Te
     return w_in, w_out
 
 
+def istft_masked_bwd(g_wave: torch.Tensor, mag: torch.Tensor, phase: torch.Tensor, mask: torch.Tensor, which: int,
+                     domain: str = "linear", hop: int = 322, win: int = 644,
+                     window: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Backward of :func:`istft_masked` for one branch: ``g_wave [B, length]`` = dL/d(resynthesised wave) of the
+    mask-in (``which = 0``) or mask-out (``which = 1``) signal -> ``dL/d mask [B, Fm, Tm]``
+    (LMACLoss backward, loss_function.py:36-47)."""
+    _lib.init()
+    mag = _req(mag, torch.float32, "mag")
+    phase = _req(phase, torch.float32, "phase")
+    mask = _req(mask, torch.float32, "mask")
+    g_wave = _req(g_wave, torch.float32, "g_wave")
+    B, _, T = mag.shape
+    if mag.shape != phase.shape or mag.dim() != 3 or mag.shape[1] != NBIN:
+        raise ValueError("mag / phase must be [B, 513, T]")
+    if mask.dim() != 3 or mask.shape[0] != B or mask.shape[1] > NBIN or mask.shape[2] > T:
+        raise ValueError("mask must be [B, Fm<=513, Tm<=T]")
+    if g_wave.dim() != 2 or g_wave.shape[0] != B:
+        raise ValueError("g_wave must be [B, length]")
+    length = g_wave.shape[1]
+    if T != 1 + length // hop:
+        raise ValueError("T does not match length // hop + 1")
+    mode = {"linear": 1, "log1p": 2}[domain]
+    dmask = torch.empty_like(mask)
+    rc = _lib.lib().advh_istft_masked_bwd(g_wave.data_ptr(), length, mag.data_ptr(), phase.data_ptr(), mask.data_ptr(),
+                                          mask.shape[1], mask.shape[2], mode, int(which), dmask.data_ptr(), B, T, length, hop,
+                                          win, _ptr(window), _stream())
+    _lib.check(rc, "advh_istft_masked_bwd")
+    return dmask
+
+
 def istft_complex(spec: torch.Tensor, length: int, hop: int = 322, win: int = 644,
                   window: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``spec [B,513,T] complex64 -> wave [B, length]`` (audioprocessor.py:117-131)."""

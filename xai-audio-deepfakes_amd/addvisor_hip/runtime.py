@@ -106,5 +106,13 @@ def hip_embedder():
     return _state["hip_emb"]
 
 
+def hip_embedder_grad():
+    """Forward-with-saves + input-gradient engine on the HIP embedder singleton (LMACLoss backward, attributions)."""
+    if "hip_eg" not in _state:
+        from .embedder_grad import EmbedderGrad
+        _state["hip_eg"] = EmbedderGrad(hip_embedder())
+    return _state["hip_eg"]
+
+
 def reset():
     _state.clear()

@@ -58,11 +58,20 @@ __device__ __forceinline__ void carve(float* smem, float*& re, float*& im, float
 }
 
 // ------------------------------------------------------------------------------------------ forward
-template <int FB>
+// ADJ = 1 turns the kernel into the ADJOINT of the masked ISTFT (the backward of loss_function.py:36-47 from the
+// resynthesised waveform to the mask): `wave` is then dL/d(resynthesised wave) [B][L]; it is divided by the
+// overlap-add window envelope, zero-extended (not reflected) to the padded signal, framed with the synthesis
+// window and transformed; with G = rfft of a frame, dL/dRe X_k = (c_k/N) Re G_k and dL/dIm X_k = (c_k/N) Im G_k
+// (c_k = 1 for k = 0, N/2 where the C2R transform ignores the imaginary part, else 2).  The epilogue chains to the
+// mask: X = a e^{i phi}, a = m M (mask-in) or (1-m) M (mask-out) [linear] / expm1(m log1p M) [log1p]; it reads
+// `mag`, `phase` (and `X` = the mask for log1p) and writes dmask[b][k][t] for k < Fm, t < Tm.
+struct AdjArgs { const float* mask; float* dmask; int Fm, Tm, mode, which; };
+
+template <int FB, int ADJ>
 __global__ __launch_bounds__(THREADS) void stft_fwd_kernel(
     const float* __restrict__ wave, long wave_stride, int n_in, int L, int hop, int win,
     const float* __restrict__ window, float* __restrict__ X, float* __restrict__ mag,
-    float* __restrict__ phase, int T) {
+    float* __restrict__ phase, int T, AdjArgs adj) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *re, *im, *smp;
     carve<FB>(smem, re, im, smp);
@@ -75,10 +84,23 @@ __global__ __launch_bounds__(THREADS) void stft_fwd_kernel(
     const float* w = wave + (long)b * wave_stride;
     for (int i = tid; i < span; i += THREADS) {
         int src = tA * hop + left + i - NFFT / 2;
-        if (src < 0) src = -src;
-        if (src >= L) src = 2 * (L - 1) - src;
         float v = 0.f;
-        if (src >= 0 && src < n_in && src < L) v = w[src];
+        if (ADJ) {
+            if (src >= 0 && src < L && src < n_in) {
+                const int pp = tA * hop + left + i;       // padded-signal coordinate
+                const int R = (win + hop - 1) / hop, thi = (pp - left) / hop;
+                float env = 0.f;
+                for (int r = 0; r < R; ++r) {
+                    int t = thi - r, j = pp - left - t * hop;
+                    if (t >= 0 && t < T && j >= 0 && j < win) { float ww = window ? window[j] : 1.f; env += ww * ww; }
+                }
+                v = env > 1e-11f ? w[src] / env : 0.f;
+            }
+        } else {
+            if (src < 0) src = -src;
+            if (src >= L) src = 2 * (L - 1) - src;
+            if (src >= 0 && src < n_in && src < L) v = w[src];
+        }
         smp[i] = v;
     }
     __syncthreads();
@@ -132,6 +154,29 @@ __global__ __launch_bounds__(THREADS) void stft_fwd_kernel(
         if (tl >= nvalid) continue;
         float xr = re[tl * FFT_ROW + fidx(k)], xi = im[tl * FFT_ROW + fidx(k)];
         long o = ((long)b * NBIN + k) * T + tA + tl;
+        if (ADJ) {
+            const int t = tA + tl;
+            if (k >= adj.Fm || t >= adj.Tm) continue;
+            const bool edge = k == 0 || k == NFFT / 2;
+            const float sc = (edge ? 1.f : 2.f) / NFFT;
+            float sn, cs;
+            sincosf(phase[o], &sn, &cs);
+            const float da = sc * (xr * cs + (edge ? 0.f : xi * sn));       // dL/da, a = |X| after masking
+            const long om = ((long)b * adj.Fm + k) * adj.Tm + t;
+            const float M = mag[o];
+            float dm;
+            if (adj.mode == ADVH_MASK_LINEAR) {
+                dm = adj.which ? -M * da : M * da;
+            } else {                                       // a = expm1(m' log1p M), m' = m or 1 - m
+                float m = adj.mask[om];
+                if (adj.which) m = 1.f - m;
+                const float lg = log1pf(M);
+                dm = lg * expf(m * lg) * da;
+                if (adj.which) dm = -dm;
+            }
+            adj.dmask[om] = dm;
+            continue;
+        }
         if (X) reinterpret_cast<float2*>(X)[o] = make_float2(xr, xi);
         if (mag) mag[o] = hypotf(xr, xi);
         if (phase) phase[o] = atan2f(xi, xr);
@@ -271,7 +316,8 @@ extern "C" int advh_init(void) {
     }
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_twiddle), host, sizeof(host)) != hipSuccess) return ADVH_ELAUNCH;
     const int maxlds = 160 * 1024;
-    const void* big[] = {(const void*)stft_fwd_kernel<16>, (const void*)stft_fwd_kernel<8>, (const void*)istft_kernel<0, 16>,
+    const void* big[] = {(const void*)stft_fwd_kernel<16, 0>, (const void*)stft_fwd_kernel<8, 0>, (const void*)stft_fwd_kernel<16, 1>,
+                         (const void*)stft_fwd_kernel<8, 1>, (const void*)istft_kernel<0, 16>,
                          (const void*)istft_kernel<1, 16>, (const void*)istft_kernel<0, 8>, (const void*)istft_kernel<1, 8>};
     for (const void* f : big)
         if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, maxlds) != hipSuccess) return ADVH_ELAUNCH;
@@ -297,12 +343,36 @@ extern "C" int advh_stft_forward(const float* wave, int64_t wave_stride, int n_i
     if (!wave || n_in <= 0 || wave_stride < (n_in < L ? n_in : L)) return ADVH_EINVAL;
     const int FB = g_stft_fb;
     dim3 grid((T + FB - 1) / FB, B);
+    const AdjArgs none = {nullptr, nullptr, 0, 0, 0, 0};
     if (FB == 8)
-        hipLaunchKernelGGL(stft_fwd_kernel<8>, grid, dim3(THREADS), lds_bytes(8, hop, win), (hipStream_t)stream, wave,
-                           (long)wave_stride, n_in, L, hop, win, window, X, mag, phase, T);
+        hipLaunchKernelGGL((stft_fwd_kernel<8, 0>), grid, dim3(THREADS), lds_bytes(8, hop, win), (hipStream_t)stream, wave,
+                           (long)wave_stride, n_in, L, hop, win, window, X, mag, phase, T, none);
     else
-        hipLaunchKernelGGL(stft_fwd_kernel<16>, grid, dim3(THREADS), lds_bytes(16, hop, win), (hipStream_t)stream, wave,
-                           (long)wave_stride, n_in, L, hop, win, window, X, mag, phase, T);
+        hipLaunchKernelGGL((stft_fwd_kernel<16, 0>), grid, dim3(THREADS), lds_bytes(16, hop, win), (hipStream_t)stream, wave,
+                           (long)wave_stride, n_in, L, hop, win, window, X, mag, phase, T, none);
+    return hipGetLastError() == hipSuccess ? ADVH_OK : ADVH_ELAUNCH;
+}
+
+extern "C" int advh_istft_masked_bwd(const float* g_wave, int64_t g_stride, const float* mag, const float* phase,
+                                     const float* mask, int Fm, int Tm, int mode, int which, float* dmask, int B, int T,
+                                     int L, int hop, int win, const float* window, advh_stream_t stream) {
+    int rc = check_frame_args(B, T, L, hop, win);
+    if (rc) return rc;
+    if (!g_wave || !mag || !phase || !dmask || g_stride < L || Fm <= 0 || Tm <= 0 || Fm > NBIN || Tm > T) return ADVH_EINVAL;
+    if (mode != ADVH_MASK_LINEAR && mode != ADVH_MASK_LOG1P) return ADVH_EINVAL;
+    if (mode == ADVH_MASK_LOG1P && !mask) return ADVH_EINVAL;
+    if (which != 0 && which != 1) return ADVH_EINVAL;
+    const int FB = g_stft_fb;
+    dim3 grid((Tm + FB - 1) / FB, B);
+    const AdjArgs adj = {mask, dmask, Fm, Tm, mode, which};
+    float* magp = const_cast<float*>(mag);
+    float* php = const_cast<float*>(phase);
+    if (FB == 8)
+        hipLaunchKernelGGL((stft_fwd_kernel<8, 1>), grid, dim3(THREADS), lds_bytes(8, hop, win), (hipStream_t)stream, g_wave,
+                           (long)g_stride, L, L, hop, win, window, (float*)nullptr, magp, php, T, adj);
+    else
+        hipLaunchKernelGGL((stft_fwd_kernel<16, 1>), grid, dim3(THREADS), lds_bytes(16, hop, win), (hipStream_t)stream, g_wave,
+                           (long)g_stride, L, L, hop, win, window, (float*)nullptr, magp, php, T, adj);
     return hipGetLastError() == hipSuccess ? ADVH_OK : ADVH_ELAUNCH;
 }
 

@@ -1,6 +1,7 @@
-"""Drop-in for the reference's ``loss_function`` module (loss_function.py:1-77): LMAC loss forward on the
-HIP path.  Gradients flow to ``w_raw``; the backward through the frozen embedder / ISTFT to the mask
-is SURVEY.md §8(f) rank 1 (not built yet), so ``total_loss`` is not differentiable w.r.t. ``xhat``."""
+"""Drop-in for the reference's ``loss_function`` module (loss_function.py:1-77): LMAC loss on the HIP path,
+forward and backward.  ``total_loss.backward()`` (train_addvisor.py:376) delivers gradients to ``w_raw`` (torch)
+and to ``xhat`` -- through the ISTFT adjoint and the frozen embedder's input-gradient chain, both HIP
+(addvisor_hip/lmac_loss.py) -- so the reference's training loop drives a mask decoder unchanged."""
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -28,17 +29,20 @@ class LMACLoss(nn.Module):
         outside; linear masking; two resyntheses; two classifier passes."""
         ap = audio_processor
         L = int(ap.audio_length * ap.sampling_rate)
-        m = xhat.squeeze(1).to(device, torch.float32).contiguous()
+        m = xhat.squeeze(1).to(device, torch.float32)
         mag = X_stft_power.to(device, torch.float32).contiguous()
         ph = X_stft_phase.to(device, torch.float32).contiguous()
-        w_in, w_out = _ops.istft_masked(mag, ph, m.detach(), L, domain="linear", hop=ap.hop_length, win=ap.win_length)
-        emb = _rt.hip_embedder()
-        _, l_rel, _ = emb.forward(w_in, L, want_hidden=False)
-        _, l_irr, _ = emb.forward(w_out, L, want_hidden=False)
         cp = class_pred.to(device, torch.float32)
-        l_in = F.binary_cross_entropy_with_logits(l_rel, cp)
-        l_out = F.binary_cross_entropy_with_logits(l_irr, 1 - cp)
-        reg_l1 = m.abs().mean()
-        losses = torch.stack([l_in, l_out, reg_l1])
+        if torch.is_grad_enabled() and m.requires_grad:
+            from addvisor_hip.lmac_loss import lmac_terms
+            losses = lmac_terms(m, mag, ph, cp, _rt.hip_embedder_grad(), L, hop=ap.hop_length, win=ap.win_length)
+        else:
+            w_in, w_out = _ops.istft_masked(mag, ph, m.detach(), L, domain="linear", hop=ap.hop_length, win=ap.win_length)
+            emb = _rt.hip_embedder()
+            _, l_rel, _ = emb.forward(w_in, L, want_hidden=False)
+            _, l_irr, _ = emb.forward(w_out, L, want_hidden=False)
+            l_in = F.binary_cross_entropy_with_logits(l_rel, cp)
+            l_out = F.binary_cross_entropy_with_logits(l_irr, 1 - cp)
+            losses = torch.stack([l_in, l_out, m.abs().mean()])
         w = self.w.to(device)
         return torch.sum(w * losses), losses, self.w
