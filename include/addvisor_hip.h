@@ -75,6 +75,14 @@ int advh_istft_masked(const float* mag, const float* phase, const float* mask, i
 int advh_istft_c64(const float* spec, float* wave, int64_t wave_stride, int B, int T, int L, int hop, int win,
                    const float* window, advh_stream_t stream);
 
+/* Band-swap resynthesis (the data generator of hifigan.py:196-228 and train_logReg_swapping.py:64-92; SURVEY.md §8(f)
+ * rank 2): for band z in [0, nbands) the bins [k0 + z*kw, k0 + (z+1)*kw) of the complex64 spectrogram spec_a
+ * [B][513][T] are replaced by those of spec_b and the result is inverted (torch.istft semantics as advh_istft_c64);
+ * waves [nbands][B][L], band stride band_stride >= B*wave_stride elements.  One launch, grid z = band.            */
+int advh_istft_bandswap(const float* spec_a, const float* spec_b, int k0, int kw, int nbands, float* waves,
+                        int64_t wave_stride, int64_t band_stride, int B, int T, int L, int hop, int win,
+                        const float* window, advh_stream_t stream);
+
 /* Backward of advh_istft_masked from ONE resynthesised waveform to the mask (LMACLoss backward,
  * loss_function.py:36-47 / SURVEY.md §8(f) rank 1): g_wave = dL/d wave [B][L] (row stride g_stride), which = 0 for
  * the mask-in branch (a = m M), 1 for mask-out (a = (1 - m) M); dmask [B][Fm][Tm] is overwritten.  `mask` is only

@@ -63,3 +63,22 @@ def align_waveforms(ref_wav: torch.Tensor, deg_wav: torch.Tensor):
         ref_a = ref_wav[..., : deg_a.shape[-1]]
     n = min(ref_a.shape[-1], deg_a.shape[-1])
     return ref_a[..., :n], deg_a[..., :n]
+
+
+def band_swap_hann(s_ref: torch.Tensor, s_voc: torch.Tensor, band_hz: int = 1000, f_max: int = 8000):
+    """hifigan.py:190-228 -- Hann-1024 / hop-256 STFT of the aligned original and vocoded signals; for every
+    1 kHz band the complex bins with ``start <= f < end`` on ``linspace(0, 8000, 513)`` are taken from the vocoded
+    spectrogram; ``torch.istft`` (no ``length``).  Returns ``(waves [n_bands, L'], leakage [n_bands])``."""
+    window = torch.hann_window(1024)
+    kw = dict(n_fft=1024, hop_length=256, win_length=1024, window=window)
+    X_r = torch.stft(s_ref, return_complex=True, **kw)
+    X_v = torch.stft(s_voc, return_complex=True, **kw)
+    freqs = torch.linspace(0, 8000, X_r.shape[0])
+    waves, leak = [], []
+    for start in range(0, f_max, band_hz):
+        mask = (freqs >= start) & (freqs < start + band_hz)
+        X_c = X_r.clone()
+        X_c[mask, :] = X_v[mask, :]
+        leak.append(torch.mean((X_c[~mask].abs() - X_r[~mask].abs()) ** 2).item())
+        waves.append(torch.istft(X_c, **kw))
+    return torch.stack(waves), torch.tensor(leak)

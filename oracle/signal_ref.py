@@ -111,3 +111,19 @@ def mel_spectrogram(audio: torch.Tensor, sr=16000, hop=256, win=1024, n_mels=80,
     fb = mel_filterbank_slaney(n_mels, n_fft, sr, f_min, f_max).to(audio.dtype)
     mel = torch.matmul(X.abs().transpose(-1, -2), fb).transpose(-1, -2)
     return torch.log(torch.clamp(mel, min=1e-5))
+
+
+def band_swap_rect(w_real: torch.Tensor, w_vocoded: torch.Tensor, audio_length=5, band_hz: int = 1000, f_max: int = 8000):
+    """train_logReg_swapping.py:64-81 -- AudioProcessor STFTs (rectangular 644 window, hop 322) of one real and one
+    vocoded clip; per 1 kHz band the bins ``start <= f < end`` on ``linspace(0, 8000, 513)`` come from the vocoded one;
+    ``compute_invert_stft``.  ``[L] , [L] -> [n_bands, audio_length * 16000]``."""
+    X_o = compute_stft(w_real, audio_length=audio_length)[0]
+    X_v = compute_stft(w_vocoded, audio_length=audio_length)[0]
+    freqs = torch.linspace(0, 16000 / 2, X_o.shape[0])
+    out = []
+    for start in range(0, f_max, band_hz):
+        mask = (freqs >= start) & (freqs < start + band_hz)
+        X_c = X_o.clone()
+        X_c[mask, :] = X_v[mask, :]
+        out.append(compute_invert_stft(X_c, audio_length=audio_length))
+    return torch.stack(out)

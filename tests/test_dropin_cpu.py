@@ -158,3 +158,50 @@ def test_unet_training_forward_under_ddp_gloo_world2():
     res = [q.get(timeout=180) for _ in procs]
     [p.join(60) for p in procs]
     assert all(ok for _, ok in res) and all(p.exitcode == 0 for p in procs)
+
+
+def test_wavio_round_trip_and_formats(tmp_path):
+    from addvisor_hip.wavio import read_wav, write_wav
+    r = np.random.Generator(np.random.PCG64(4))
+    x = torch.from_numpy(r.uniform(-0.9, 0.9, size=(2, 1001)).astype(np.float32))
+    write_wav(tmp_path / "f.wav", x, 22050)                                   # float32, stereo, odd frame count
+    a, sr = read_wav(tmp_path / "f.wav")
+    assert sr == 22050 and torch.equal(a, x)
+    write_wav(tmp_path / "p.wav", x[0], 16000, encoding="pcm16")
+    b, sr = read_wav(tmp_path / "p.wav")
+    assert sr == 16000 and b.shape == (1, 1001) and (b[0] - x[0]).abs().max() <= 1 / 32768 + 1e-7
+    with wave.open(str(tmp_path / "p.wav"), "rb") as w:                      # the stdlib reader agrees on the PCM file
+        assert (w.getframerate(), w.getnchannels(), w.getsampwidth(), w.getnframes()) == (16000, 1, 2, 1001)
+    v = np.round(x[0].numpy() * 8388608.0).astype(np.int32)                   # hand-made 24-bit PCM
+    raw = b"".join(struct.pack("<i", int(s))[:3] for s in v)
+    hdr = struct.pack("<HHIIHH", 1, 1, 8000, 24000, 3, 24)
+    (tmp_path / "t.wav").write_bytes(b"RIFF" + struct.pack("<I", 36 + len(raw)) + b"WAVEfmt " + struct.pack("<I", 16) + hdr
+                                     + b"data" + struct.pack("<I", len(raw)) + raw + b"\x00")
+    c, sr = read_wav(tmp_path / "t.wav")
+    assert sr == 8000 and (c[0] - x[0]).abs().max() < 1e-6
+    (tmp_path / "bad.wav").write_bytes(b"nope")
+    with pytest.raises(ValueError):
+        read_wav(tmp_path / "bad.wav")
+
+
+def test_logreg_trainer_and_eer(tmp_path):
+    """train_logReg_swapping.py:105-128 on separable synthetic features; the .joblib feeds runtime.classifier()."""
+    import train_logReg_swapping as T
+    from addvisor_hip import runtime
+    r = np.random.Generator(np.random.PCG64(8))
+    y = np.array(([0] + [1] * 8) * 40)
+    X = r.standard_normal((y.size, 24)).astype(np.float32) + 2.5 * y[:, None] * np.linspace(-1, 1, 24)[None, :]
+    model, acc, eer = T.train_logReg_timeswap(X, y, out_path=str(tmp_path / "ckpt" / "lr.joblib"))
+    assert acc > 0.95 and 0.0 <= eer < 0.1
+    s = model.predict_proba(X)[:, 1]
+    assert abs(T.equal_error_rate(y, s) - T.equal_error_rate(y, s * 0.5)) < 1e-9       # EER is rank-based
+    os.environ["ADDVISOR_LOGREG"] = str(tmp_path / "ckpt" / "lr.joblib")
+    try:
+        runtime.reset()
+        clf = runtime.classifier()
+        assert np.allclose(np.asarray(clf.coef_).reshape(-1), model.coef_.reshape(-1))
+    finally:
+        os.environ.pop("ADDVISOR_LOGREG", None)
+        runtime.reset()
+    (tmp_path / "m.txt").write_text("a.wav,x\nb.wav,y,z\n")
+    assert T.find_all_files(str(tmp_path / "m.txt")) == ["a.wav", "b.wav"]

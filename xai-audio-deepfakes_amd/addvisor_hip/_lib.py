@@ -64,6 +64,7 @@ SIGNATURES = {
     "advh_attr_finalize": (_i, [_p, _p, _p, _i, _i64, _p]),
     "advh_time_mask": (_i, [_p, _p, _p, _p, _p, _i, _i64, _p]),
     "advh_istft_masked_bwd": (_i, [_p, _i64, _p, _p, _p, _i, _i, _i, _i, _p, _i, _i, _i, _i, _i, _p, _p]),
+    "advh_istft_bandswap": (_i, [_p, _p, _i, _i, _i, _p, _i64, _i64, _i, _i, _i, _i, _i, _p, _p]),
     "advh_conv_taps_tile": (_i, [_i, _i, _i]),
     "advh_conv_taps_lds_bytes": (_i, [_i, _i, _i]),
     "advh_conv_taps_f16": (_i, [_p, _i, _p]),

@@ -122,6 +122,34 @@ def istft_masked_bwd(g_wave: torch.Tensor, mag: torch.Tensor, phase: torch.Tenso
     return dmask
 
 
+def istft_bandswap(spec_a: torch.Tensor, spec_b: torch.Tensor, length: int, k0: int = 0, kw: int = 64, nbands: int = 8,
+                   hop: int = 322, win: int = 644, window: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Band-swap resynthesis (hifigan.py:196-228, train_logReg_swapping.py:64-92): for each band ``z`` the bins
+    ``[k0 + z*kw, k0 + (z+1)*kw)`` of ``spec_a`` are replaced by ``spec_b``'s and the spectrogram is inverted;
+    ``[nbands, B, length]`` fp32, one launch.  With 513 bins on ``linspace(0, 8000, 513)`` the reference's 1 kHz bands
+    ``freqs >= 1000 z and freqs < 1000 (z+1)`` are exactly ``k0 = 0, kw = 64`` (bin 512 = 8 kHz belongs to no band)."""
+    _lib.init()
+    for sp in (spec_a, spec_b):
+        if not torch.is_complex(sp):
+            raise ValueError("ISTFT expects complex input!")
+        if sp.dtype != torch.complex64 or sp.dim() != 3 or sp.shape[1] != NBIN:
+            raise ValueError("spec must be complex64 [B, 513, T]")
+    if spec_a.shape != spec_b.shape:
+        raise ValueError("the two spectrograms must have the same shape")
+    B, _, T = spec_a.shape
+    if T != 1 + length // hop:
+        raise ValueError("T does not match length // hop + 1")
+    if window is not None:
+        window = _req(window, torch.float32, "window")
+    a = torch.view_as_real(spec_a.contiguous())
+    b = torch.view_as_real(spec_b.contiguous())
+    out = torch.empty((nbands, B, length), dtype=torch.float32, device=spec_a.device)
+    rc = _lib.lib().advh_istft_bandswap(a.data_ptr(), b.data_ptr(), k0, kw, nbands, out.data_ptr(), length, B * length, B, T,
+                                        length, hop, win, _ptr(window), _stream())
+    _lib.check(rc, "advh_istft_bandswap")
+    return out
+
+
 def istft_complex(spec: torch.Tensor, length: int, hop: int = 322, win: int = 644,
                   window: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``spec [B,513,T] complex64 -> wave [B, length]`` (audioprocessor.py:117-131)."""

@@ -1,7 +1,5 @@
 """Drop-in for the reference's ``audioprocessor`` module (audioprocessor.py:1-131): same class, method
 names, argument meaning and errors; STFT / ISTFT / embedder run as hand-written gfx950 kernels."""
-import wave as _wave
-
 import numpy as np
 import torch
 import torch.nn.functional as F
@@ -25,20 +23,9 @@ wav2vec2.eval()
 
 
 def _read_wav(path):
-    """Mono PCM WAV reader (the reference uses torchaudio.load, audioprocessor.py:50)."""
-    with _wave.open(path, "rb") as w:
-        sr, n, ch, sw = w.getframerate(), w.getnframes(), w.getnchannels(), w.getsampwidth()
-        raw = w.readframes(n)
-    if sw == 2:
-        a = np.frombuffer(raw, dtype="<i2").astype(np.float32) / 32768.0
-    elif sw == 4:
-        a = np.frombuffer(raw, dtype="<i4").astype(np.float32) / 2147483648.0
-    elif sw == 1:
-        a = (np.frombuffer(raw, dtype=np.uint8).astype(np.float32) - 128.0) / 128.0
-    else:
-        raise ValueError(f"unsupported sample width {sw}")
-    a = a.reshape(-1, ch).T                       # [channels, frames] like torchaudio
-    return torch.from_numpy(np.ascontiguousarray(a)), sr
+    """WAV reader (the reference uses torchaudio.load, audioprocessor.py:50): ``[channels, frames]`` fp32, rate."""
+    from addvisor_hip.wavio import read_wav
+    return read_wav(path)
 
 
 class AudioProcessor:

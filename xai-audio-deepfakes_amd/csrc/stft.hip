@@ -184,19 +184,21 @@ __global__ __launch_bounds__(THREADS) void stft_fwd_kernel(
 }
 
 // ------------------------------------------------------------------------------------------ inverse
-// SRC 0: mag/phase (+ optional mask, mode), SRC 1: complex64 spectrogram
+// SRC 0: mag/phase (+ optional mask, mode), SRC 1: complex64 spectrogram, SRC 2: band swap of two complex64
+// spectrograms (hifigan.py:208-222, train_logReg_swapping.py:70-81): grid z = band, bins [Fm + z*Tm, Fm + (z+1)*Tm)
+// come from `phase` (the vocoded signal), all others from `mag` (the original); output z at out0 + z * out1_stride.
 template <int SRC, int FB>
 __global__ __launch_bounds__(THREADS) void istft_kernel(
     const float* __restrict__ mag, const float* __restrict__ phase, const float* __restrict__ mask,
     int Fm, int Tm, int mode, int which0, float* __restrict__ out0, float* __restrict__ out1,
-    long wave_stride, int T, int L, int hop, int win, int R, const float* __restrict__ window) {
+    long wave_stride, int T, int L, int hop, int win, int R, const float* __restrict__ window, long zstride) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *re, *im, *acc;
     carve<FB>(smem, re, im, acc);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int b = blockIdx.y, g = blockIdx.x;
     const int which = which0 + blockIdx.z;            // 0: mask-in, 1: mask-out
-    float* out = (blockIdx.z == 0 ? out0 : out1) + (long)b * wave_stride;
+    float* out = (SRC == 2 ? out0 + (long)blockIdx.z * zstride : (blockIdx.z == 0 ? out0 : out1)) + (long)b * wave_stride;
     const int left = (NFFT - win) / 2;
     const int S = FB - R + 1;                         // complete hop-segments this workgroup emits
     const int tA = g * S - (R - 1);                   // first frame it transforms (may be < 0)
@@ -210,6 +212,10 @@ __global__ __launch_bounds__(THREADS) void istft_kernel(
             long o = ((long)b * NBIN + k) * T + t;
             if (SRC == 1) {
                 float2 v = reinterpret_cast<const float2*>(mag)[o];
+                xr = v.x; xi = v.y;
+            } else if (SRC == 2) {
+                const int lo = Fm + (int)blockIdx.z * Tm;
+                float2 v = reinterpret_cast<const float2*>((k >= lo && k < lo + Tm) ? phase : mag)[o];
                 xr = v.x; xi = v.y;
             } else {
                 float a = mag[o], ph = phase[o];
@@ -318,6 +324,7 @@ extern "C" int advh_init(void) {
     const int maxlds = 160 * 1024;
     const void* big[] = {(const void*)stft_fwd_kernel<16, 0>, (const void*)stft_fwd_kernel<8, 0>, (const void*)stft_fwd_kernel<16, 1>,
                          (const void*)stft_fwd_kernel<8, 1>, (const void*)istft_kernel<0, 16>,
+                         (const void*)istft_kernel<2, 16>, (const void*)istft_kernel<2, 8>,
                          (const void*)istft_kernel<1, 16>, (const void*)istft_kernel<0, 8>, (const void*)istft_kernel<1, 8>};
     for (const void* f : big)
         if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, maxlds) != hipSuccess) return ADVH_ELAUNCH;
@@ -378,7 +385,7 @@ extern "C" int advh_istft_masked_bwd(const float* g_wave, int64_t g_stride, cons
 
 static int launch_istft(int src, const float* a, const float* ph, const float* mask, int Fm, int Tm, int mode,
                         float* o0, float* o1, int64_t ws, int B, int T, int L, int hop, int win,
-                        const float* window, advh_stream_t stream) {
+                        const float* window, advh_stream_t stream, int nbands = 0, int64_t zstride = 0) {
     int rc = check_frame_args(B, T, L, hop, win);
     if (rc) return rc;
     const int R = (win + hop - 1) / hop;
@@ -390,13 +397,15 @@ static int launch_istft(int src, const float* a, const float* ph, const float* m
     if (!o0 && !o1) return ADVH_EINVAL;
     if (!o0) { which0 = 1; p0 = o1; nz = 1; }
     else if (!o1) { nz = 1; }
+    if (src == 2) nz = nbands;
     const int nG = (NFFT / 2 + L - left + S * hop - 1) / (S * hop);
     dim3 grid(nG, B, nz);
 #define ISTFT_LAUNCH(SRC_, FB_)                                                                                          \
     hipLaunchKernelGGL((istft_kernel<SRC_, FB_>), grid, dim3(THREADS), lds_bytes(FB_, hop, win), (hipStream_t)stream, a, ph,  \
-                       mask, Fm, Tm, mode, which0, p0, p1, (long)ws, T, L, hop, win, R, window)
+                       mask, Fm, Tm, mode, which0, p0, p1, (long)ws, T, L, hop, win, R, window, (long)zstride)
     if (src == 0) { if (FB == 8) ISTFT_LAUNCH(0, 8); else ISTFT_LAUNCH(0, 16); }
-    else { if (FB == 8) ISTFT_LAUNCH(1, 8); else ISTFT_LAUNCH(1, 16); }
+    else if (src == 1) { if (FB == 8) ISTFT_LAUNCH(1, 8); else ISTFT_LAUNCH(1, 16); }
+    else { if (FB == 8) ISTFT_LAUNCH(2, 8); else ISTFT_LAUNCH(2, 16); }
 #undef ISTFT_LAUNCH
     return hipGetLastError() == hipSuccess ? ADVH_OK : ADVH_ELAUNCH;
 }
@@ -409,6 +418,16 @@ extern "C" int advh_istft_masked(const float* mag, const float* phase, const flo
     if (mode < 0 || mode > ADVH_MASK_LOG1P) return ADVH_EINVAL;
     if (mode == ADVH_MASK_NONE && wave_out) return ADVH_EINVAL;
     return launch_istft(0, mag, phase, mask, Fm, Tm, mode, wave_in, wave_out, wave_stride, B, T, L, hop, win, window, stream);
+}
+
+extern "C" int advh_istft_bandswap(const float* spec_a, const float* spec_b, int k0, int kw, int nbands, float* waves,
+                                   int64_t wave_stride, int64_t band_stride, int B, int T, int L, int hop, int win,
+                                   const float* window, advh_stream_t stream) {
+    if (!spec_a || !spec_b || !waves || wave_stride < L || nbands <= 0 || nbands > 65535 || k0 < 0 || kw <= 0 ||
+        k0 + (long)nbands * kw > NBIN || band_stride < (int64_t)B * wave_stride)
+        return ADVH_EINVAL;
+    return launch_istft(2, spec_a, spec_b, nullptr, k0, kw, ADVH_MASK_NONE, waves, nullptr, wave_stride, B, T, L, hop, win, window,
+                        stream, nbands, band_stride);
 }
 
 extern "C" int advh_istft_c64(const float* spec, float* wave, int64_t wave_stride, int B, int T, int L, int hop, int win,
