@@ -156,6 +156,9 @@ typedef struct advh_gemm_desc {
        the epilogue moves 16 bytes of fp16 per lane.  Requires N, n_div, o_c0 and every o_s* stride % 8 == 0
        (checked).  wide = 0: packed row R is channel R.                                                     */
     int32_t wide;
+    /* row pitch of W in elements; 0 = Ktot.  Lets a launch (or grid-z batch) reduce over a K-slice of a wider
+       K-major matrix: the split-K weight-gradient GEMMs of the U-Net training step.                       */
+    int64_t w_ld;
 } advh_gemm_desc;
 
 int advh_gemm_f16(const advh_gemm_desc* desc, int tile, advh_stream_t stream);
@@ -296,6 +299,43 @@ typedef struct advh_taps_desc {
 int advh_conv_taps_tile(int C, int ntap, int span);       /* positions per workgroup tile (128/192/256); 0 = does not fit */
 int advh_conv_taps_lds_bytes(int C, int ntap, int span);  /* weights + two line buffers; -1 = does not fit           */
 int advh_conv_taps_f16(const advh_taps_desc* d, int C, advh_stream_t stream);
+
+/* ---- training step of the U-Net mask decoder (addvisor.py:12-84 under train_addvisor.py:364-378)
+ * Maps are zero-haloed channels-last fp16 [B][H+2PH][W+2PW][C]; only interiors are read for statistics / written.
+ * BatchNorm2d in training mode (batch statistics over B*H*W, eps 1e-5) around LeakyReLU(slope):
+ *   advh_bn_stats     sums[0..C) = sum z, sums[C..2C) = sum z^2 (deterministic two-stage; partial: advh_bn_partial_count()*2*C floats)
+ *   advh_bn_apply     a = lrelu(coef[c]*z + coef[C+c])                        coef = [scale | shift | mean | invstd], 4*C floats
+ *   advh_bn_bwd_sums  with dy^ = g_a * lrelu'(scale*z+shift), z^ = (z-mean)*invstd: sums = [sum dy^ | sum dy^ z^]
+ *   advh_bn_bwd_apply dz = coef_b[c]*(dy^ - coef_b[C+c] - z^*coef_b[2C+c]) written at dz + d_c0 + b*d_sB + h*d_sH + w*d_sW
+ *                     (interior coordinates; a dense map or the zero-upsampled grid of a strided layer), coef_b = [k1 | m1 | m2].
+ *   g_a (same geometry as z) is fp16 or, with g_f32 = 1, fp32: the backward subtracts g_a's per-channel mean, so the
+ *   dgrad GEMM that produces it stores its fp32 accumulators (out_f).                                            */
+typedef struct advh_map_geom { int B, H, W, C, PH, PW; } advh_map_geom;
+int advh_bn_partial_count(void);
+int advh_bn_stats(const void* z, const advh_map_geom* g, float* partial, float* sums, advh_stream_t stream);
+int advh_bn_apply(const void* z, const advh_map_geom* g, const float* coef, float slope, void* a, advh_stream_t stream);
+int advh_bn_bwd_sums(const void* z, const void* g_a, int g_f32, const advh_map_geom* g, const float* coef, float slope,
+                     float* partial, float* sums, advh_stream_t stream);
+int advh_bn_bwd_apply(const void* z, const void* g_a, int g_f32, const advh_map_geom* g, const float* coef, const float* coef_b, float slope,
+                      void* dz, int64_t d_sB, int64_t d_sH, int64_t d_sW, int64_t d_c0, advh_stream_t stream);
+/* Operand transpose for the weight-gradient GEMM (reduction over positions needs position-major operands):
+ * dst[(t*rpt + r0 + c)*ld + col0 + p] = src[b][PHs + y][PWs + x][c0 + c], p = (b*Hg + hg)*Wg + wg over the layer's common
+ * grid, (y, x) = (sy*(hg-GH) + oy[t], sx*(wg-GW) + ox[t]); zero where (y, x) is outside the source interior.  fp16.  */
+typedef struct advh_transpose_desc {
+    int B, Hg, Wg, GH, GW, H, W;
+    int Hs, Ws, PHs, PWs, Cs, c0, nC;
+    int sy, sx, ntap, oy[16], ox[16];
+    int64_t ld, col0;
+    int rpt, r0;          /* dst row of (tap t, channel c) = t*rpt + r0 + c (r0 > 0: second source of a skip concatenation) */
+} advh_transpose_desc;
+int advh_transpose_gather(const void* src, void* dst, const advh_transpose_desc* d, advh_stream_t stream);
+/* mask head backward (addvisor.py:57-60): dlogit = dmask*m*(1-m) (fp32 out), dy1[i][c] = scale*dlogit[i]*w32[c] (fp32 [total][32]). */
+int advh_unet_head_bwd(const float* dmask, const float* mask, const float* w32, float scale, int64_t total, float* dlogit,
+                       void* dy1, advh_stream_t stream);
+/* weight gradient of the 1-channel stem e1.block.0: dw[co][kh*3+kw] = sum dz[b][ho][w][co] * mag[b][2ho+kh-2][w+kw-1];
+ * dz = dense fp16 map [B][H/2+2PH][W+2PW][32]; partial: advh_bn_partial_count()*480 floats; dw [32][15] fp32.     */
+int advh_unet_stem_wgrad(const void* dz, int Fq, int Tq, int B, int H, int W, const float* mag, int PH, int PW,
+                         float* partial, float* dw, advh_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -54,7 +54,7 @@ class GemmDesc(C.Structure):
         ("n_div", C.c_int32), ("nz", C.c_int32), ("act", C.c_int32), ("slope", C.c_float),
         ("resid_f32", C.c_int32), ("ktab_identity", C.c_int32),
         ("out_h2", C.c_void_p), ("slope2", C.c_float), ("ph_r", C.c_int32), ("ph_pad", C.c_int32), ("ph_T", C.c_int32),
-        ("out_pre", C.c_void_p), ("dact_src", C.c_void_p), ("wide", C.c_int32),
+        ("out_pre", C.c_void_p), ("dact_src", C.c_void_p), ("wide", C.c_int32), ("w_ld", C.c_int64),
     ]
 
 
@@ -193,6 +193,24 @@ class GemmPlan:
         self.desc = d
         self.nsrc = len(sources)
         self.flops = 2.0 * M * N * K * nz          # algorithmic (unpadded) FLOPs of this launch
+
+    def load_weights(self, w2: torch.Tensor, bias: Optional[torch.Tensor] = None):
+        """Re-pack ``w2 [nz, N, K]`` (a tensor on the plan's device, any float dtype) into the plan's fp16 operand in
+        place, with the wide-epilogue row permutation if the plan uses it -- the per-step weight refresh of the
+        training path (no host round trip; a handful of torch copy kernels)."""
+        N, K = self.desc.N, self.K
+        assert w2.shape == (self.desc.nz, N, K) and w2.device == self.w.device, (w2.shape, (self.desc.nz, N, K))
+        if self.desc.wide:
+            if not hasattr(self, "_perm"):
+                src = packed_row_channel(self.w.shape[1])
+                keep = np.nonzero(src < N)[0]
+                self._perm = (torch.from_numpy(keep).to(self.w.device), torch.from_numpy(src[keep]).to(self.w.device))
+            dst_rows, src_rows = self._perm
+            self.w[:, dst_rows, :K] = w2.to(torch.float16)[:, src_rows]
+        else:
+            self.w[:, :N, :K] = w2.to(torch.float16)
+        if bias is not None:
+            self.bias.copy_(bias.reshape(self.bias.shape).to(torch.float32))
 
     def run(self, A0: torch.Tensor, A1: Optional[torch.Tensor] = None, *, out_h: Optional[torch.Tensor] = None,
             out_f: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None, stream: Optional[int] = None,

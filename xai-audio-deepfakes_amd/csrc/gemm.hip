@@ -223,7 +223,7 @@ __global__ __launch_bounds__(64 * WM * WN, WPE) void gemm_f16_kernel(const advh_
     }
     const _Float16* wrow[NB];
 #pragma unroll
-    for (int i = 0; i < NB; ++i) wrow[i] = Wp + (long)(n0 + ldrow + RPP * i) * p.Ktot + q * 8;
+    for (int i = 0; i < NB; ++i) wrow[i] = Wp + (long)(n0 + ldrow + RPP * i) * (p.w_ld ? p.w_ld : (long)p.Ktot) + q * 8;
 
     // ---- fragment read offsets (bytes) inside a tile: row r, logical chunk c -> (r*8 + (c ^ (r&7)))*16
     const int fr = lane & 15, fq = lane >> 4;
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(512) void gemm_f16_pipe_kernel(const advh_gemm_desc
     }
     const _Float16* wrow[NB];
 #pragma unroll
-    for (int i = 0; i < NB; ++i) wrow[i] = Wp + (long)(n0 + ldrow + 64 * i) * p.Ktot + q * 8;
+    for (int i = 0; i < NB; ++i) wrow[i] = Wp + (long)(n0 + ldrow + 64 * i) * (p.w_ld ? p.w_ld : (long)p.Ktot) + q * 8;
 
     const int fr = lane & 15, fq = lane >> 4;
     int offA[2], offB[2];
@@ -506,7 +506,7 @@ __global__ __launch_bounds__(512) void gemm_f16_ring_kernel(const advh_gemm_desc
     }
     const _Float16* wrow[NB];
 #pragma unroll
-    for (int i = 0; i < NB; ++i) wrow[i] = Wp + (long)(n0 + ldrow + 128 * i) * p.Ktot + q * 8;
+    for (int i = 0; i < NB; ++i) wrow[i] = Wp + (long)(n0 + ldrow + 128 * i) * (p.w_ld ? p.w_ld : (long)p.Ktot) + q * 8;
 
     const int fr = lane & 15, fq = lane >> 4;
     const int phys = fq ^ ((fr >> 1) & 2);

@@ -1,0 +1,334 @@
+// Training-mode kernels of the U-Net mask decoder (addvisor.py:12-84 under train_addvisor.py:364-378; SURVEY.md §8(f)
+// rank 1): batch-statistics BatchNorm forward and backward on zero-haloed channels-last fp16 maps, the operand
+// transposes of the weight-gradient GEMM, and the 1x1 sigmoid head's backward.  All HBM-bound row kernels; the
+// contractions themselves (forward conv, dgrad, wgrad) are advh_gemm_f16 launches planned in addvisor_hip/unet_train.py.
+//
+// A map is [B][Hp][Wp][C] fp16 with the interior window rows h in [PH, PH+H), w in [PW, PW+W); halo elements are zero
+// and are never written here.  Reductions over positions are two-stage and deterministic: NPART workgroups write
+// per-channel partial sums, a second kernel adds them in a fixed order in fp64.
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include "addvisor_hip.h"
+#include "common.h"
+
+namespace advh {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int NPART = 1024;
+
+struct MapGeom { int B, Hp, Wp, C, PH, PW, H, W; };
+
+__device__ __forceinline__ bool interior(const MapGeom& g, long row, int& b, int& h, int& w) {
+    w = (int)(row % g.Wp);
+    long r = row / g.Wp;
+    h = (int)(r % g.Hp);
+    b = (int)(r / g.Hp);
+    return h >= g.PH && h < g.PH + g.H && w >= g.PW && w < g.PW + g.W;
+}
+
+// MODE 0: (sum z, sum z^2).  MODE 1 (BatchNorm backward): with y = scale*z + shift, dy^ = g * lrelu'(y),
+// z^ = (z - mean) * invstd: (sum dy^, sum dy^ z^).  coef = [scale | shift | mean | invstd] (4 x C floats).
+// One thread owns 8 channels of every (NPART * lanes_per_chunk)-th row.
+__device__ __forceinline__ void load_g8(const void* g, bool f32, long off, float (&o)[8]) {
+    if (f32) {
+        const float4 a = *(const float4*)((const float*)g + off), b = *(const float4*)((const float*)g + off + 4);
+        o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+    } else {
+        const f16x8 v = *(const f16x8*)((const _Float16*)g + off);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (float)v[j];
+    }
+}
+
+// The incoming gradient g may be fp32: BatchNorm's backward subtracts its per-channel mean, so an fp16 g would lose
+// exactly the part that survives (the dgrad GEMM accumulates in fp32 and can store fp32).
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_partial_kernel(const _Float16* __restrict__ z, const void* __restrict__ g, bool g_f32,
+                                                         const float* __restrict__ coef, float slope, MapGeom gm,
+                                                         float* __restrict__ partial /*[NPART][2][C]*/) {
+    __shared__ float red[256 * 16];
+    const int CH = gm.C / 8, tid = threadIdx.x;
+    const int ch = tid % CH, rl = tid / CH, RL = 256 / CH;       // CH in {4, 8, 16, 32, 64}
+    const long rows = (long)gm.B * gm.Hp * gm.Wp;
+    float s1[8], s2[8], sc[8], sh[8], mu[8], is[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        s1[j] = s2[j] = 0.f;
+        if (MODE == 1) {
+            const int c = ch * 8 + j;
+            sc[j] = coef[c]; sh[j] = coef[gm.C + c]; mu[j] = coef[2 * gm.C + c]; is[j] = coef[3 * gm.C + c];
+        }
+    }
+    if (rl < RL) {
+        for (long row = (long)blockIdx.x * RL + rl; row < rows; row += (long)gridDim.x * RL) {
+            int b, h, w;
+            if (!interior(gm, row, b, h, w)) continue;
+            const f16x8 zv = *(const f16x8*)(z + row * gm.C + ch * 8);
+            if (MODE == 0) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { float v = (float)zv[j]; s1[j] += v; s2[j] = fmaf(v, v, s2[j]); }
+            } else {
+                float gv[8];
+                load_g8(g, g_f32, row * gm.C + ch * 8, gv);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float zz = (float)zv[j], y = fmaf(sc[j], zz, sh[j]);
+                    float d = gv[j] * (y > 0.f ? 1.f : slope);
+                    s1[j] += d;
+                    s2[j] = fmaf(d, (zz - mu[j]) * is[j], s2[j]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { red[tid * 16 + j] = s1[j]; red[tid * 16 + 8 + j] = s2[j]; }
+    __syncthreads();
+    if (tid < CH) {                                             // fixed-order sum over the row lanes of this chunk
+        for (int j = 0; j < 16; ++j) {
+            float a = 0.f;
+            for (int r = 0; r < RL; ++r) a += red[(r * CH + tid) * 16 + j];
+            partial[((long)blockIdx.x * 2 + (j >> 3)) * gm.C + tid * 8 + (j & 7)] = a;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict__ partial, int nparts, int C, float* __restrict__ sums) {
+    const int i = blockIdx.x * 256 + threadIdx.x;               // i in [0, 2C)
+    if (i >= 2 * C) return;
+    double a = 0.0;
+    for (int p = 0; p < nparts; ++p) a += (double)partial[(long)p * 2 * C + i];
+    sums[i] = (float)a;
+}
+
+// forward: a = lrelu(scale*z + shift) on the interior.  backward: dz = k1 * (dy^ - m1 - z^ * m2), written into `dst`
+// at element offset d_c0 + b*d_sB + (h-PH)*d_sH + (w-PW)*d_sW (dense map of the same or another halo, or the
+// zero-upsampled grid a strided convolution's dgrad / wgrad read).  coef_b = [k1 | m1 | m2] (3 x C floats).
+template <int BWD>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const _Float16* __restrict__ z, const void* __restrict__ g, bool g_f32,
+                                                       const float* __restrict__ coef, const float* __restrict__ coef_b,
+                                                       float slope, MapGeom gm, _Float16* __restrict__ dst, long d_sB, long d_sH,
+                                                       long d_sW, long d_c0) {
+    const int CH = gm.C / 8;
+    const long total = (long)gm.B * gm.Hp * gm.Wp * CH;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int ch = (int)(i % CH);
+    const long row = i / CH;
+    int b, h, w;
+    if (!interior(gm, row, b, h, w)) return;
+    const f16x8 zv = *(const f16x8*)(z + row * gm.C + ch * 8);
+    f16x8 o;
+    if (!BWD) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = ch * 8 + j;
+            float y = fmaf(coef[c], (float)zv[j], coef[gm.C + c]);
+            o[j] = (_Float16)(y > 0.f ? y : slope * y);
+        }
+    } else {
+        float gv[8];
+        load_g8(g, g_f32, row * gm.C + ch * 8, gv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = ch * 8 + j;
+            float zz = (float)zv[j], y = fmaf(coef[c], zz, coef[gm.C + c]);
+            float d = gv[j] * (y > 0.f ? 1.f : slope);
+            float zh = (zz - coef[2 * gm.C + c]) * coef[3 * gm.C + c];
+            o[j] = (_Float16)(coef_b[c] * (d - coef_b[gm.C + c] - zh * coef_b[2 * gm.C + c]));
+        }
+    }
+    *(f16x8*)(dst + d_c0 + (long)b * d_sB + (long)(h - gm.PH) * d_sH + (long)(w - gm.PW) * d_sW + ch * 8) = o;
+}
+
+// Operand transpose of the weight-gradient GEMM.  dst[(t*nC + c)][col0 + p] = src[b][PHs + y][PWs + x][c0 + c] with
+// p = (b*Hg + hg)*Wg + wg enumerating the COMMON grid of the layer, (y, x) = (sy*(hg-GH) + oy[t], sx*(wg-GW) + ox[t]);
+// zero where (y, x) falls outside the source interior (the source's zero padding, grid halo rows, pad columns).  One workgroup
+// moves a 64-position x 8*NC8-channel slab through LDS so both sides are 16-byte / 128-byte accesses.
+struct TrArgs {
+    int B, Hg, Wg, GH, GW, H, W;          // common grid and its interior
+    int Hs, Ws, PHs, PWs, Cs, c0, nC;     // source map interior size, halo, channel count, channel slice
+    int sy, sx, ntap, oy[16], ox[16];
+    long ld, col0;                        // dst row pitch (elements) and first column
+    int rpt, r0;                          // dst row of (tap t, channel c) = t*rpt + r0 + c
+};
+
+__global__ __launch_bounds__(256) void transpose_gather_kernel(const _Float16* __restrict__ src, _Float16* __restrict__ dst, TrArgs a) {
+    __shared__ _Float16 tile[64][72];                           // [position][channel], pitch 72 halfs = 144 B
+    const long M = (long)a.B * a.Hg * a.Wg;
+    const long p0 = (long)blockIdx.x * 64;
+    const int t = blockIdx.y, cb = blockIdx.z * 64;             // tap, first channel of this 64-channel slab
+    const int tid = threadIdx.x;
+    const int nch = min(64, a.nC - cb);                         // channels in this slab (multiple of 8, or 1..7 for a 1-channel source)
+    // gather: thread = (position tid>>2 ... 64 positions x 4 chunk-lanes), 2 chunks each
+    for (int i = tid; i < 64 * 8; i += 256) {
+        const int pl = i >> 3, ck = i & 7;
+        f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        const long p = p0 + pl;
+        if (p < M && ck * 8 < nch) {
+            const int wg = (int)(p % a.Wg);
+            const long r = p / a.Wg;
+            const int hg = (int)(r % a.Hg), b = (int)(r / a.Hg);
+            const int gy = hg - a.GH, gx = wg - a.GW;
+            const int y = a.sy * gy + a.oy[t], x = a.sx * gx + a.ox[t];
+            if (y >= 0 && y < a.Hs && x >= 0 && x < a.Ws) {
+                const _Float16* s = src + (((long)b * (a.Hs + 2 * a.PHs) + y + a.PHs) * (a.Ws + 2 * a.PWs) + x + a.PWs) * a.Cs + a.c0 + cb + ck * 8;
+                if (nch - ck * 8 >= 8) v = *(const f16x8*)s;
+                else for (int j = 0; j < nch - ck * 8; ++j) v[j] = s[j];
+            }
+        }
+        *(f16x8*)&tile[pl][ck * 8] = v;
+    }
+    __syncthreads();
+    // scatter: thread = (channel, 8-position chunk)
+    for (int i = tid; i < 64 * 8; i += 256) {
+        const int c = i >> 3, pk = i & 7;
+        if (c >= nch) continue;
+        f16x8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = tile[pk * 8 + j][c];
+        const long col = p0 + pk * 8;
+        _Float16* d = dst + ((long)t * a.rpt + a.r0 + cb + c) * a.ld + a.col0 + col;
+        if (col + 8 <= M) *(f16x8*)d = v;
+        else for (int j = 0; j < 8 && col + j < M; ++j) d[j] = v[j];
+    }
+}
+
+// mask head backward (addvisor.py:57-60): dlogit = dmask * m (1 - m); d y1[b,h,w,c] = dlogit * w[c] (fp32, scaled by
+// `scale`); dlogit itself is stored (fp32) for the weight / bias sums.
+__global__ __launch_bounds__(256) void unet_head_bwd_kernel(const float* __restrict__ dmask, const float* __restrict__ mask,
+                                                            const float* __restrict__ w32, float scale, long total,
+                                                            float* __restrict__ dlogit, float* __restrict__ dy1) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const float m = mask[i], d = dmask[i] * m * (1.f - m);
+    dlogit[i] = d;
+    const float ds = d * scale;
+#pragma unroll
+    for (int c4 = 0; c4 < 8; ++c4)
+        *(float4*)(dy1 + i * 32 + c4 * 4) = make_float4(ds * w32[c4 * 4], ds * w32[c4 * 4 + 1], ds * w32[c4 * 4 + 2], ds * w32[c4 * 4 + 3]);
+}
+
+// weight gradient of the 1-channel stem e1.block.0 (Conv2d(1, 32, (5,3), stride (2,1), padding (2,1)), addvisor.py:31):
+// dW[co][kh*3+kw] = sum_p dz[p][co] * mag[b][2ho+kh-2][w+kw-1].  Thread = (co, position lane); the 15 magnitudes of a
+// position are the same for the 32 channel threads (broadcast loads).  Two-stage deterministic reduction.
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(const _Float16* __restrict__ dz, const float* __restrict__ mag, int Fq, int Tq,
+                                                         int B, int H, int W, int PH, int PW, float* __restrict__ partial /*[NPART][480]*/) {
+    __shared__ float red[8][480];
+    const int co = threadIdx.x & 31, pl = threadIdx.x >> 5, Ho = H / 2;
+    const long total = (long)B * Ho * W;
+    float acc[15];
+#pragma unroll
+    for (int k = 0; k < 15; ++k) acc[k] = 0.f;
+    for (long i = (long)blockIdx.x * 8 + pl; i < total; i += (long)gridDim.x * 8) {
+        const int w = (int)(i % W);
+        const long r = i / W;
+        const int ho = (int)(r % Ho), b = (int)(r / Ho);
+        const float d = (float)dz[(((long)b * (Ho + 2 * PH) + ho + PH) * (W + 2 * PW) + w + PW) * 32 + co];
+#pragma unroll
+        for (int kh = 0; kh < 5; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int h = 2 * ho + kh - 2, ww = w + kw - 1;
+                const float x = (h >= 0 && h < H && ww >= 0 && ww < W) ? mag[((long)b * Fq + h) * Tq + ww] : 0.f;
+                acc[kh * 3 + kw] = fmaf(d, x, acc[kh * 3 + kw]);
+            }
+    }
+#pragma unroll
+    for (int k = 0; k < 15; ++k) red[pl][co * 15 + k] = acc[k];
+    __syncthreads();
+    for (int i = threadIdx.x; i < 480; i += 256) {
+        float a = 0.f;
+        for (int r = 0; r < 8; ++r) a += red[r][i];
+        partial[(long)blockIdx.x * 480 + i] = a;
+    }
+}
+
+}  // namespace advh
+
+using namespace advh;
+
+extern "C" int advh_unet_stem_wgrad(const void* dz, int Fq, int Tq, int B, int H, int W, const float* mag, int PH, int PW,
+                                    float* partial, float* dw, advh_stream_t stream) {
+    if (!dz || !mag || !partial || !dw || B <= 0 || H <= 0 || (H & 1) || W <= 0 || H > Fq || W > Tq || PH < 0 || PW < 0) return ADVH_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(stem_wgrad_kernel, dim3(NPART), dim3(256), 0, s, (const _Float16*)dz, mag, Fq, Tq, B, H, W, PH, PW, partial);
+    hipLaunchKernelGGL(bn_reduce_kernel, dim3(2), dim3(256), 0, s, partial, NPART, 240, dw);
+    return ADVH_LAUNCH_CHECK();
+}
+
+static bool geom_ok(const advh_map_geom* g) {
+    return g && g->B > 0 && g->H > 0 && g->W > 0 && g->PH >= 0 && g->PW >= 0 && g->C >= 32 && g->C <= 512 && (g->C & (g->C - 1)) == 0;
+}
+static MapGeom mk(const advh_map_geom* g) { return MapGeom{g->B, g->H + 2 * g->PH, g->W + 2 * g->PW, g->C, g->PH, g->PW, g->H, g->W}; }
+
+extern "C" int advh_bn_partial_count(void) { return NPART; }
+
+extern "C" int advh_bn_stats(const void* z, const advh_map_geom* g, float* partial, float* sums, advh_stream_t stream) {
+    if (!z || !partial || !sums || !geom_ok(g)) return ADVH_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(NPART), dim3(256), 0, s, (const _Float16*)z, (const void*)nullptr, false,
+                       (const float*)nullptr, 0.f, mk(g), partial);
+    hipLaunchKernelGGL(bn_reduce_kernel, dim3((2 * g->C + 255) / 256), dim3(256), 0, s, partial, NPART, g->C, sums);
+    return ADVH_LAUNCH_CHECK();
+}
+
+extern "C" int advh_bn_apply(const void* z, const advh_map_geom* g, const float* coef, float slope, void* a, advh_stream_t stream) {
+    if (!z || !a || !coef || !geom_ok(g)) return ADVH_EINVAL;
+    MapGeom m = mk(g);
+    const long total = (long)m.B * m.Hp * m.Wp * (m.C / 8);
+    hipLaunchKernelGGL(bn_apply_kernel<0>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const _Float16*)z, (const void*)nullptr, false, coef, (const float*)nullptr, slope, m, (_Float16*)a,
+                       (long)m.Hp * m.Wp * m.C, (long)m.Wp * m.C, (long)m.C, ((long)m.PH * m.Wp + m.PW) * m.C);
+    return ADVH_LAUNCH_CHECK();
+}
+
+extern "C" int advh_bn_bwd_sums(const void* z, const void* g_a, int g_f32, const advh_map_geom* g, const float* coef, float slope,
+                                float* partial, float* sums, advh_stream_t stream) {
+    if (!z || !g_a || !coef || !partial || !sums || !geom_ok(g)) return ADVH_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(bn_partial_kernel<1>, dim3(NPART), dim3(256), 0, s, (const _Float16*)z, g_a, g_f32 != 0, coef, slope,
+                       mk(g), partial);
+    hipLaunchKernelGGL(bn_reduce_kernel, dim3((2 * g->C + 255) / 256), dim3(256), 0, s, partial, NPART, g->C, sums);
+    return ADVH_LAUNCH_CHECK();
+}
+
+extern "C" int advh_bn_bwd_apply(const void* z, const void* g_a, int g_f32, const advh_map_geom* g, const float* coef, const float* coef_b,
+                                 float slope, void* dz, int64_t d_sB, int64_t d_sH, int64_t d_sW, int64_t d_c0,
+                                 advh_stream_t stream) {
+    if (!z || !g_a || !dz || !coef || !coef_b || !geom_ok(g)) return ADVH_EINVAL;
+    if ((d_sB | d_sH | d_sW | d_c0) & 7) return ADVH_EINVAL;
+    MapGeom m = mk(g);
+    const long total = (long)m.B * m.Hp * m.Wp * (m.C / 8);
+    hipLaunchKernelGGL(bn_apply_kernel<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const _Float16*)z, g_a, g_f32 != 0, coef, coef_b, slope, m, (_Float16*)dz, (long)d_sB, (long)d_sH,
+                       (long)d_sW, (long)d_c0);
+    return ADVH_LAUNCH_CHECK();
+}
+
+extern "C" int advh_transpose_gather(const void* src, void* dst, const advh_transpose_desc* d, advh_stream_t stream) {
+    if (!src || !dst || !d || d->B <= 0 || d->Hg <= 0 || d->Wg <= 0 || d->ntap <= 0 || d->ntap > 16 || d->nC <= 0 ||
+        d->c0 < 0 || d->c0 + d->nC > d->Cs || d->sy <= 0 || d->sx <= 0 || (d->ld & 7) || (d->col0 & 7) || d->r0 < 0 ||
+        d->rpt < d->r0 + d->nC)
+        return ADVH_EINVAL;
+    if (d->nC >= 8 && ((d->nC & 7) || (d->c0 & 7) || (d->Cs & 7))) return ADVH_EINVAL;
+    TrArgs a;
+    a.B = d->B; a.Hg = d->Hg; a.Wg = d->Wg; a.GH = d->GH; a.GW = d->GW; a.H = d->H; a.W = d->W;
+    a.Hs = d->Hs; a.Ws = d->Ws; a.PHs = d->PHs; a.PWs = d->PWs; a.Cs = d->Cs; a.c0 = d->c0; a.nC = d->nC;
+    a.sy = d->sy; a.sx = d->sx; a.ntap = d->ntap;
+    for (int t = 0; t < 16; ++t) { a.oy[t] = d->oy[t]; a.ox[t] = d->ox[t]; }
+    a.ld = d->ld; a.col0 = d->col0; a.rpt = d->rpt; a.r0 = d->r0;
+    const long M = (long)d->B * d->Hg * d->Wg;
+    if (d->col0 + ((M + 7) / 8) * 8 > d->ld) return ADVH_EINVAL;
+    dim3 grid((unsigned)((M + 63) / 64), d->ntap, (d->nC + 63) / 64);
+    hipLaunchKernelGGL(transpose_gather_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const _Float16*)src, (_Float16*)dst, a);
+    return ADVH_LAUNCH_CHECK();
+}
+
+extern "C" int advh_unet_head_bwd(const float* dmask, const float* mask, const float* w32, float scale, int64_t total,
+                                  float* dlogit, void* dy1, advh_stream_t stream) {
+    if (!dmask || !mask || !w32 || !dlogit || !dy1 || total <= 0) return ADVH_EINVAL;
+    hipLaunchKernelGGL(unet_head_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dmask,
+                       mask, w32, scale, (long)total, dlogit, (float*)dy1);
+    return ADVH_LAUNCH_CHECK();
+}
