@@ -332,6 +332,9 @@ int advh_transpose_gather(const void* src, void* dst, const advh_transpose_desc*
 /* mask head backward (addvisor.py:57-60): dlogit = dmask*m*(1-m) (fp32 out), dy1[i][c] = scale*dlogit[i]*w32[c] (fp32 [total][32]). */
 int advh_unet_head_bwd(const float* dmask, const float* mask, const float* w32, float scale, int64_t total, float* dlogit,
                        void* dy1, advh_stream_t stream);
+/* mask head weight / bias gradient: dw33[c] = sum_i dlogit[i]*y1[i][c] for c < 32, dw33[32] = sum_i dlogit[i]; y1 fp16
+ * [total][32]; partial: advh_bn_partial_count()*64 floats; dw33: 64 floats (33 used).                               */
+int advh_unet_head_wgrad(const float* dlogit, const void* y1, int64_t total, float* partial, float* dw33, advh_stream_t stream);
 /* weight gradient of the 1-channel stem e1.block.0: dw[co][kh*3+kw] = sum dz[b][ho][w][co] * mag[b][2ho+kh-2][w+kw-1];
  * dz = dense fp16 map [B][H/2+2PH][W+2PW][32]; partial: advh_bn_partial_count()*480 floats; dw [32][15] fp32.     */
 int advh_unet_stem_wgrad(const void* dz, int Fq, int Tq, int B, int H, int W, const float* mag, int PH, int PW,

@@ -1,6 +1,7 @@
 """Drop-in for the reference's ``addvisor`` module (addvisor.py:1-84): ``ConvBlock`` / ``UNet`` with the
 reference's parameter names (so checkpoints load with ``load_state_dict``), forward on the HIP
 implicit-GEMM kernels.  ``ADDvisor`` is the name LMAC_metrics.py:6 imports."""
+import os
 import warnings
 
 import torch
@@ -74,13 +75,18 @@ class UNet(nn.Module):
             raise RuntimeError(f"U-Net skip connections need F % 16 == 0 and T % 4 == 0, got {Fq}x{Tq}")
         dev = torch.device("cuda")
         if self.training and torch.is_grad_enabled():
-            # Training step (train_addvisor.py:364-378): the mask must carry an autograd graph back to the U-Net
-            # parameters.  The decoder's own forward / backward (7 % of the step's FLOPs) runs on torch's GPU
-            # convolutions with batch-statistics BatchNorm, exactly the reference modules; the loss it feeds
-            # (loss_function.LMACLoss: ISTFT x2, frozen embedder x2 and their backward) is the HIP path.
-            # Hand-written dgrad / wgrad kernels for the decoder are SURVEY.md §8(f) rank 1's remainder.
-            self._hip = None                                   # weights change: repack before the next HIP forward
-            mask = self._forward_autograd(x4.to(self.mask_head[0].weight.device, torch.float32))
+            # Training step (train_addvisor.py:364-378): the mask carries an autograd graph back to the parameters.
+            # On a GPU that graph is ONE autograd.Function over the HIP training kernels (addvisor_hip/unet_train.py:
+            # batch-statistics BatchNorm, dgrad / wgrad as implicit GEMMs); parameters stay ordinary nn.Parameters, so
+            # torch optimisers and DistributedDataParallel (RCCL gradient all-reduce) work unchanged.  On the CPU
+            # (the gloo rehearsal of the data-parallel step) or with ADDVISOR_UNET_TRAIN=torch the registered torch
+            # modules run instead.
+            self._hip = None                                   # weights change: repack before the next inference forward
+            pdev = self.mask_head[0].weight.device
+            if pdev.type == "cuda" and os.environ.get("ADDVISOR_UNET_TRAIN", "hip") != "torch":
+                mask = self._forward_hip_train(x4.to(pdev, torch.float32))
+            else:
+                mask = self._forward_autograd(x4.to(pdev, torch.float32))
             return mask[:, 0] if squeeze else mask
         if self.training and not self._warned:
             warnings.warn("UNet is in training mode but gradients are disabled; the HIP path uses eval-mode "
@@ -88,6 +94,15 @@ class UNet(nn.Module):
             self._warned = True
         mask = self._engine(dev).forward(x4[:, 0].to(dev, torch.float32).contiguous(), H=Fq, W=Tq)
         return mask if squeeze else mask[:, None]
+
+    def _forward_hip_train(self, x):
+        from addvisor_hip.unet_train import HipUNetTrain
+        names = [k for k, _ in self.named_parameters()]
+        tensors = {k: v.detach() for k, v in self.state_dict(keep_vars=True).items()}     # live storage of params and buffers
+        if getattr(self, "_train_engine", None) is None or self._train_engine.dev != x.device:
+            self._train_engine = HipUNetTrain(tensors, x.device)
+        self._train_engine.p = tensors
+        return _UNetTrainFn.apply(self._train_engine, x, names, *[p for _, p in self.named_parameters()])
 
     def _forward_autograd(self, x):
         """addvisor.py:62-84 on the registered torch modules (encoder, dilated bottleneck, transposed-conv
@@ -102,6 +117,21 @@ class UNet(nn.Module):
         y2 = self.d2(torch.cat([self.up2(y3), x1], 1))
         y1 = self.d1(torch.cat([self.up1(y2), x], 1))
         return self.mask_head(y1)
+
+
+class _UNetTrainFn(torch.autograd.Function):
+    """mask = UNet(x) in train() mode and its backward, both on the HIP kernels."""
+
+    @staticmethod
+    def forward(ctx, engine, x, names, *params):
+        ctx.engine, ctx.names, ctx.shapes = engine, names, [p.shape for p in params]
+        B, _, H, W = x.shape
+        return engine.forward(x[:, 0].contiguous(), H=H, W=W)[:, None]
+
+    @staticmethod
+    def backward(ctx, gmask):
+        grads = ctx.engine.backward(gmask[:, 0])
+        return (None, None, None) + tuple(grads[k].reshape(s) for k, s in zip(ctx.names, ctx.shapes))
 
 
 ADDvisor = UNet

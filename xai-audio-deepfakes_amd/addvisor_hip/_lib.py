@@ -72,6 +72,7 @@ SIGNATURES = {
     "advh_bn_bwd_apply": (_i, [_p, _p, _i, _p, _p, _p, _f, _p, _i64, _i64, _i64, _i64, _p]),
     "advh_transpose_gather": (_i, [_p, _p, _p, _p]),
     "advh_unet_head_bwd": (_i, [_p, _p, _p, _f, _i64, _p, _p, _p]),
+    "advh_unet_head_wgrad": (_i, [_p, _p, _i64, _p, _p, _p]),
     "advh_unet_stem_wgrad": (_i, [_p, _i, _i, _i, _i, _i, _p, _i, _i, _p, _p, _p]),
     "advh_conv_taps_tile": (_i, [_i, _i, _i]),
     "advh_conv_taps_lds_bytes": (_i, [_i, _i, _i]),

@@ -100,21 +100,24 @@ class _SplitKGemm:
     """Weight-gradient product ``out[z][m][n] = sum_{k in slice z} A[m][k + off] * W[n][k]`` on ``advh_gemm_f16``:
     A and W are position-major fp16 matrices on the device (``advh_transpose_gather`` outputs)."""
 
-    def __init__(self, Mrows: int, N: int, Kc: int, nz: int, a_ld: int, a_col: int, w_ld: int, device):
-        assert Kc % G.BK == 0 and a_ld % 8 == 0 and a_col % 8 == 0 and a_col >= 0 and w_ld % 8 == 0
-        self.tile, _ = G.pick_tile(N, Mrows)
+    def __init__(self, Mrows: int, N: int, Kc: int, nz: int, a_ld: int, a_col: int, w_ld: int, device, groups: int = 1,
+                 group_off: int = 0):
+        """``groups`` > 1: the A rows come in ``groups`` blocks of ``Mrows`` (the vertical taps of a convolution); block
+        ``i`` reads the same matrix rows shifted by ``i * group_off`` columns (the tap's K offset), so all taps are one launch."""
+        assert Kc % G.BK == 0 and a_ld % 8 == 0 and a_col % 8 == 0 and a_col >= 0 and w_ld % 8 == 0 and group_off % 8 == 0
+        self.tile, _ = G.pick_tile(N, Mrows * groups)
         self.ktab = torch.arange(Kc // 8, dtype=torch.int32, device=device)
         d = G.GemmDesc()
-        d.M, d.N, d.Ktot, d.w_rows = Mrows, N, Kc, N
-        d.Hg, d.Wg = 1, Mrows
-        d.h0, d.h1, d.w0, d.w1 = 0, 1, 0, Mrows
+        d.M, d.N, d.Ktot, d.w_rows = Mrows * groups, N, Kc, N
+        d.Hg, d.Wg = groups, Mrows
+        d.h0, d.h1, d.w0, d.w1 = 0, groups, 0, Mrows
         d.halo_zero = 0
-        d.a_sB[0], d.a_sH[0], d.a_sW[0], d.a_c0[0], d.a_sZ[0] = 0, 0, a_ld // 8, a_col // 8, Kc // 8
+        d.a_sB[0], d.a_sH[0], d.a_sW[0], d.a_c0[0], d.a_sZ[0] = 0, group_off // 8, a_ld // 8, a_col // 8, Kc // 8
         d.w_sZ, d.bias_sZ, d.w_ld = Kc, 0, w_ld
-        d.o_sB, d.o_sH, d.o_sW, d.o_c0, d.o_sNhi, d.o_sZ = 0, 0, N, 0, 0, Mrows * N
+        d.o_sB, d.o_sH, d.o_sW, d.o_c0, d.o_sNhi, d.o_sZ = 0, Mrows * N, N, 0, 0, Mrows * groups * N
         d.n_div, d.nz, d.act, d.slope = G.round_up(N, 4), nz, 0, 0.0
         d.ktab_identity, d.wide = 1, 0
-        self.desc, self.flops = d, 2.0 * Mrows * N * Kc * nz
+        self.desc, self.flops = d, 2.0 * Mrows * groups * N * Kc * nz
 
     def run(self, A: torch.Tensor, W: torch.Tensor, out_f: torch.Tensor):
         d = self.desc
@@ -227,13 +230,13 @@ class HipUNetTrain:
         Hg, Wg, GH = Hd + (KH - 1) * dh, G.round_up(Wd, 8), ph
         Mg = B * Hg * Wg
         Mrows = KW * Cin
-        nz, Kc = _split_k(Mrows, Cout, Mg)
+        nz, Kc = _split_k(KH * Mrows, Cout, Mg)
         g_lo, g_hi = ph * Wg, ((KH - 1) * dh - ph) * Wg + 64
         a_ld = g_lo + nz * Kc + g_hi
         L["XT"] = torch.zeros(Mrows, a_ld, dtype=torch.float16, device=dev)
         L["dzT"] = torch.zeros(Cout, nz * Kc, dtype=torch.float16, device=dev)
-        L["wpart"] = torch.empty(KH, nz, Mrows, Cout, dtype=torch.float32, device=dev)
-        L["wg"] = [_SplitKGemm(Mrows, Cout, Kc, nz, a_ld, g_lo + (i * dh - ph) * Wg, nz * Kc, dev) for i in range(KH)]
+        L["wpart"] = torch.empty(nz, KH, Mrows, Cout, dtype=torch.float32, device=dev)
+        L["wg"] = _SplitKGemm(Mrows, Cout, Kc, nz, a_ld, g_lo - ph * Wg, nz * Kc, dev, groups=KH, group_off=dh * Wg)
         tds, r0 = [], 0
         for s in srcs:
             f = m[s]
@@ -356,9 +359,11 @@ class HipUNetTrain:
         y1, gy1 = m["y1"], g["y1"]
         _lib.check(lib.advh_unet_head_bwd(dmask.data_ptr(), ws["mask"].data_ptr(), hw.data_ptr(), S, B * H * W, ws["dlogit"].data_ptr(),
                                           gy1.t.data_ptr(), st), "advh_unet_head_bwd")
-        dl = ws["dlogit"].view(-1)
-        grads["mask_head.0.weight"] = torch.mv(y1.t.view(-1, 32).float().t(), dl).view(1, 32, 1, 1)
-        grads["mask_head.0.bias"] = dl.sum().view(1)
+        dw33 = torch.empty(64, dtype=torch.float32, device=self.dev)
+        _lib.check(lib.advh_unet_head_wgrad(ws["dlogit"].data_ptr(), y1.t.data_ptr(), B * H * W, ws["partial"].data_ptr(),
+                                            dw33.data_ptr(), st), "advh_unet_head_wgrad")
+        grads["mask_head.0.weight"] = dw33[:32].clone().view(1, 32, 1, 1)
+        grads["mask_head.0.bias"] = dw33[32:33].clone()
         fresh = set()                                            # skip maps whose gradient has been written once already
         for L in reversed(ws["layers"]):
             if L["kind"] == "up":
@@ -392,10 +397,9 @@ class HipUNetTrain:
             for sname, td in L["x_tr"]:
                 self._tr(m[sname].t, L["XT"], td)
             self._tr(dzm.t, L["dzT"], L["dz_tr"])
-            for i in range(KH):
-                L["wg"][i].run(L["XT"], L["dzT"], L["wpart"][i])
+            L["wg"].run(L["XT"], L["dzT"], L["wpart"])
             Cin, Cout = L["Cin"], z[dst].C
-            dw = L["wpart"].sum(1).view(KH, KW, Cin, Cout).permute(3, 2, 0, 1) / S              # [Cout, Cin, KH, KW]
+            dw = L["wpart"].sum(0).view(KH, KW, Cin, Cout).permute(3, 2, 0, 1) / S              # [Cout, Cin, KH, KW]
             grads[L["cname"] + ".weight"] = dw[:, :w.shape[1]].contiguous()
             # ---- dgrad
             wt = w.permute(1, 0, 2, 3).flip(2, 3)                                               # [Cin, Cout, KH, KW]

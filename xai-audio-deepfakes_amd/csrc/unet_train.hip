@@ -93,12 +93,15 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const _Float16* __restr
     }
 }
 
+// second stage: one wavefront per output, lanes stride over the partials, fixed shuffle tree in fp64 (deterministic)
 __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict__ partial, int nparts, int C, float* __restrict__ sums) {
-    const int i = blockIdx.x * 256 + threadIdx.x;               // i in [0, 2C)
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;      // i in [0, 2C)
     if (i >= 2 * C) return;
     double a = 0.0;
-    for (int p = 0; p < nparts; ++p) a += (double)partial[(long)p * 2 * C + i];
-    sums[i] = (float)a;
+    for (int p = lane; p < nparts; p += 64) a += (double)partial[(long)p * 2 * C + i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+    if (lane == 0) sums[i] = (float)a;
 }
 
 // forward: a = lrelu(scale*z + shift) on the interior.  backward: dz = k1 * (dy^ - m1 - z^ * m2), written into `dst`
@@ -209,6 +212,33 @@ __global__ __launch_bounds__(256) void unet_head_bwd_kernel(const float* __restr
         *(float4*)(dy1 + i * 32 + c4 * 4) = make_float4(ds * w32[c4 * 4], ds * w32[c4 * 4 + 1], ds * w32[c4 * 4 + 2], ds * w32[c4 * 4 + 3]);
 }
 
+// weight / bias gradient of the 1x1 mask head: dw[c] = sum_i dlogit[i] * y1[i][c] (c < 32), dw[32] = sum_i dlogit[i].
+// Thread = (8-channel chunk, row lane); partial [NPART][64] (33 used), reduced by bn_reduce_kernel with C = 32.
+__global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict__ dlogit, const _Float16* __restrict__ y1, long total,
+                                                         float* __restrict__ partial) {
+    __shared__ float red[64][36];
+    const int ch = threadIdx.x & 3, rl = threadIdx.x >> 2;
+    float acc[8], sd = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    for (long i = (long)blockIdx.x * 64 + rl; i < total; i += (long)gridDim.x * 64) {
+        const float d = dlogit[i];
+        const f16x8 v = *(const f16x8*)(y1 + i * 32 + ch * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = fmaf(d, (float)v[j], acc[j]);
+        if (ch == 0) sd += d;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[rl][ch * 8 + j] = acc[j];
+    if (ch == 0) red[rl][32] = sd;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        float a = 0.f;
+        if (threadIdx.x < 33) for (int r = 0; r < 64; ++r) a += red[r][threadIdx.x];
+        partial[(long)blockIdx.x * 64 + threadIdx.x] = a;
+    }
+}
+
 // weight gradient of the 1-channel stem e1.block.0 (Conv2d(1, 32, (5,3), stride (2,1), padding (2,1)), addvisor.py:31):
 // dW[co][kh*3+kw] = sum_p dz[p][co] * mag[b][2ho+kh-2][w+kw-1].  Thread = (co, position lane); the 15 magnitudes of a
 // position are the same for the 32 channel threads (broadcast loads).  Two-stage deterministic reduction.
@@ -248,12 +278,21 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const _Float16* __restr
 
 using namespace advh;
 
+extern "C" int advh_unet_head_wgrad(const float* dlogit, const void* y1, int64_t total, float* partial, float* dw33,
+                                    advh_stream_t stream) {
+    if (!dlogit || !y1 || !partial || !dw33 || total <= 0) return ADVH_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(head_wgrad_kernel, dim3(NPART), dim3(256), 0, s, dlogit, (const _Float16*)y1, (long)total, partial);
+    hipLaunchKernelGGL(bn_reduce_kernel, dim3(16), dim3(256), 0, s, partial, NPART, 32, dw33);    // 64 outputs, 33 used
+    return ADVH_LAUNCH_CHECK();
+}
+
 extern "C" int advh_unet_stem_wgrad(const void* dz, int Fq, int Tq, int B, int H, int W, const float* mag, int PH, int PW,
                                     float* partial, float* dw, advh_stream_t stream) {
     if (!dz || !mag || !partial || !dw || B <= 0 || H <= 0 || (H & 1) || W <= 0 || H > Fq || W > Tq || PH < 0 || PW < 0) return ADVH_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(stem_wgrad_kernel, dim3(NPART), dim3(256), 0, s, (const _Float16*)dz, mag, Fq, Tq, B, H, W, PH, PW, partial);
-    hipLaunchKernelGGL(bn_reduce_kernel, dim3(2), dim3(256), 0, s, partial, NPART, 240, dw);
+    hipLaunchKernelGGL(bn_reduce_kernel, dim3(120), dim3(256), 0, s, partial, NPART, 240, dw);
     return ADVH_LAUNCH_CHECK();
 }
 
@@ -269,7 +308,7 @@ extern "C" int advh_bn_stats(const void* z, const advh_map_geom* g, float* parti
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(NPART), dim3(256), 0, s, (const _Float16*)z, (const void*)nullptr, false,
                        (const float*)nullptr, 0.f, mk(g), partial);
-    hipLaunchKernelGGL(bn_reduce_kernel, dim3((2 * g->C + 255) / 256), dim3(256), 0, s, partial, NPART, g->C, sums);
+    hipLaunchKernelGGL(bn_reduce_kernel, dim3((2 * g->C + 3) / 4), dim3(256), 0, s, partial, NPART, g->C, sums);
     return ADVH_LAUNCH_CHECK();
 }
 
@@ -289,7 +328,7 @@ extern "C" int advh_bn_bwd_sums(const void* z, const void* g_a, int g_f32, const
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(bn_partial_kernel<1>, dim3(NPART), dim3(256), 0, s, (const _Float16*)z, g_a, g_f32 != 0, coef, slope,
                        mk(g), partial);
-    hipLaunchKernelGGL(bn_reduce_kernel, dim3((2 * g->C + 255) / 256), dim3(256), 0, s, partial, NPART, g->C, sums);
+    hipLaunchKernelGGL(bn_reduce_kernel, dim3((2 * g->C + 3) / 4), dim3(256), 0, s, partial, NPART, g->C, sums);
     return ADVH_LAUNCH_CHECK();
 }
 
