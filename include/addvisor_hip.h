@@ -312,6 +312,13 @@ int advh_conv_taps_f16(const advh_taps_desc* d, int C, advh_stream_t stream);
  *   dgrad GEMM that produces it stores its fp32 accumulators (out_f).                                            */
 typedef struct advh_map_geom { int B, H, W, C, PH, PW; } advh_map_geom;
 int advh_bn_partial_count(void);
+/* per-channel coefficients from the reduced sums: forward coef (and the nn.BatchNorm2d train-mode update of the running
+ * buffers: momentum, unbiased variance, num_batches_tracked += 1; all three NULL to skip), backward coef_b and the
+ * affine gradients dgamma = sum dy^ z^ * inv_scale, dbeta = sum dy^ * inv_scale (n = B*H*W).                       */
+int advh_bn_coef(const float* sums, const float* gamma, const float* beta, int C, float n, float eps, float momentum,
+                 float* running_mean, float* running_var, int64_t* num_batches_tracked, float* coef, advh_stream_t stream);
+int advh_bn_bwd_coef(const float* sums, const float* coef, int C, float n, float inv_scale, float* coef_b, float* dgamma,
+                     float* dbeta, advh_stream_t stream);
 int advh_bn_stats(const void* z, const advh_map_geom* g, float* partial, float* sums, advh_stream_t stream);
 int advh_bn_apply(const void* z, const advh_map_geom* g, const float* coef, float slope, void* a, advh_stream_t stream);
 int advh_bn_bwd_sums(const void* z, const void* g_a, int g_f32, const advh_map_geom* g, const float* coef, float slope,
@@ -329,9 +336,10 @@ typedef struct advh_transpose_desc {
     int rpt, r0;          /* dst row of (tap t, channel c) = t*rpt + r0 + c (r0 > 0: second source of a skip concatenation) */
 } advh_transpose_desc;
 int advh_transpose_gather(const void* src, void* dst, const advh_transpose_desc* d, advh_stream_t stream);
-/* mask head backward (addvisor.py:57-60): dlogit = dmask*m*(1-m) (fp32 out), dy1[i][c] = scale*dlogit[i]*w32[c] (fp32 [total][32]). */
+/* mask head backward (addvisor.py:57-60): dlogit = dmask*m*(1-m) (fp32 out), dy1[i][c] = scale*dlogit[i]*w32[c]
+ * ([total][32], fp32 if dy_f32 else fp16). */
 int advh_unet_head_bwd(const float* dmask, const float* mask, const float* w32, float scale, int64_t total, float* dlogit,
-                       void* dy1, advh_stream_t stream);
+                       void* dy1, int dy_f32, advh_stream_t stream);
 /* mask head weight / bias gradient: dw33[c] = sum_i dlogit[i]*y1[i][c] for c < 32, dw33[32] = sum_i dlogit[i]; y1 fp16
  * [total][32]; partial: advh_bn_partial_count()*64 floats; dw33: 64 floats (33 used).                               */
 int advh_unet_head_wgrad(const float* dlogit, const void* y1, int64_t total, float* partial, float* dw33, advh_stream_t stream);

@@ -104,6 +104,33 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict_
     if (lane == 0) sums[i] = (float)a;
 }
 
+// per-channel coefficients from the reduced sums (one thread per channel): replaces a dozen tiny tensor ops per layer.
+// forward: coef = [scale | shift | mean | invstd], running statistics updated as nn.BatchNorm2d does in train() mode
+// (momentum, unbiased variance).  backward: coef_b = [k1 | m1 | m2], dgamma = sum dy^ z^ / S, dbeta = sum dy^ / S.
+__global__ void bn_coef_kernel(const float* __restrict__ sums, const float* __restrict__ gamma, const float* __restrict__ beta, int C,
+                               float n, float eps, float momentum, float* __restrict__ rmean, float* __restrict__ rvar,
+                               long* __restrict__ nbt, float* __restrict__ coef) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && nbt) *nbt += 1;
+    if (c >= C) return;
+    const float mean = sums[c] / n;
+    const float var = fmaxf(sums[C + c] / n - mean * mean, 0.f);
+    const float invstd = rsqrtf(var + eps), scale = gamma[c] * invstd;
+    coef[c] = scale; coef[C + c] = beta[c] - mean * scale; coef[2 * C + c] = mean; coef[3 * C + c] = invstd;
+    if (rmean) {
+        rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
+        rvar[c] = (1.f - momentum) * rvar[c] + momentum * var * (n / fmaxf(n - 1.f, 1.f));
+    }
+}
+
+__global__ void bn_bwd_coef_kernel(const float* __restrict__ sums, const float* __restrict__ coef, int C, float n, float inv_scale,
+                                   float* __restrict__ coef_b, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    coef_b[c] = coef[c]; coef_b[C + c] = sums[c] / n; coef_b[2 * C + c] = sums[C + c] / n;
+    dbeta[c] = sums[c] * inv_scale; dgamma[c] = sums[C + c] * inv_scale;
+}
+
 // forward: a = lrelu(scale*z + shift) on the interior.  backward: dz = k1 * (dy^ - m1 - z^ * m2), written into `dst`
 // at element offset d_c0 + b*d_sB + (h-PH)*d_sH + (w-PW)*d_sW (dense map of the same or another halo, or the
 // zero-upsampled grid a strided convolution's dgrad / wgrad read).  coef_b = [k1 | m1 | m2] (3 x C floats).
@@ -157,14 +184,15 @@ struct TrArgs {
 };
 
 __global__ __launch_bounds__(256) void transpose_gather_kernel(const _Float16* __restrict__ src, _Float16* __restrict__ dst, TrArgs a) {
-    __shared__ _Float16 tile[64][72];                           // [position][channel], pitch 72 halfs = 144 B
+    // [position][channel] tile, 144-byte rows; the 16-byte chunk ck of row r sits at slot ck ^ ((r >> 3) & 7) so that the
+    // transposing 4-byte reads below (8 rows of one 8-row group x 4 channel pairs per 32-lane half) hit 32 distinct banks
+    __shared__ __attribute__((aligned(16))) _Float16 tile[64][72];
     const long M = (long)a.B * a.Hg * a.Wg;
     const long p0 = (long)blockIdx.x * 64;
     const int t = blockIdx.y, cb = blockIdx.z * 64;             // tap, first channel of this 64-channel slab
     const int tid = threadIdx.x;
-    const int nch = min(64, a.nC - cb);                         // channels in this slab (multiple of 8, or 1..7 for a 1-channel source)
-    // gather: thread = (position tid>>2 ... 64 positions x 4 chunk-lanes), 2 chunks each
-    for (int i = tid; i < 64 * 8; i += 256) {
+    const int nch = min(64, a.nC - cb);
+    for (int i = tid; i < 64 * 8; i += 256) {                   // gather: 8 lanes read the 128 contiguous bytes of one position
         const int pl = i >> 3, ck = i & 7;
         f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
         const long p = p0 + pl;
@@ -172,25 +200,34 @@ __global__ __launch_bounds__(256) void transpose_gather_kernel(const _Float16* _
             const int wg = (int)(p % a.Wg);
             const long r = p / a.Wg;
             const int hg = (int)(r % a.Hg), b = (int)(r / a.Hg);
-            const int gy = hg - a.GH, gx = wg - a.GW;
-            const int y = a.sy * gy + a.oy[t], x = a.sx * gx + a.ox[t];
+            const int y = a.sy * (hg - a.GH) + a.oy[t], x = a.sx * (wg - a.GW) + a.ox[t];
             if (y >= 0 && y < a.Hs && x >= 0 && x < a.Ws) {
                 const _Float16* s = src + (((long)b * (a.Hs + 2 * a.PHs) + y + a.PHs) * (a.Ws + 2 * a.PWs) + x + a.PWs) * a.Cs + a.c0 + cb + ck * 8;
                 if (nch - ck * 8 >= 8) v = *(const f16x8*)s;
                 else for (int j = 0; j < nch - ck * 8; ++j) v[j] = s[j];
             }
         }
-        *(f16x8*)&tile[pl][ck * 8] = v;
+        *(f16x8*)&tile[pl][(ck ^ ((pl >> 3) & 7)) * 8] = v;
     }
     __syncthreads();
-    // scatter: thread = (channel, 8-position chunk)
-    for (int i = tid; i < 64 * 8; i += 256) {
-        const int c = i >> 3, pk = i & 7;
+    // scatter: lane = (channel pair within a quad, 8-position group, quad); 8 dword reads -> two 16-byte stores; a wave
+    // writes 128 contiguous bytes (64 positions) of 16 channel rows
+    const int lane = tid & 63, wv = tid >> 6;
+    const int pk = (lane >> 2) & 7, cq = wv * 2 + (lane >> 5), c2 = cq * 4 + (lane & 3);
+    unsigned w[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) w[j] = *(const unsigned*)&tile[pk * 8 + j][((cq ^ pk) * 4 + (lane & 3)) * 2];
+    const long col = p0 + pk * 8;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int c = 2 * c2 + e;
         if (c >= nch) continue;
         f16x8 v;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = tile[pk * 8 + j][c];
-        const long col = p0 + pk * 8;
+        for (int j = 0; j < 8; ++j) {
+            const unsigned short h = e ? (unsigned short)(w[j] >> 16) : (unsigned short)(w[j] & 0xffffu);
+            v[j] = __builtin_bit_cast(_Float16, h);
+        }
         _Float16* d = dst + ((long)t * a.rpt + a.r0 + cb + c) * a.ld + a.col0 + col;
         if (col + 8 <= M) *(f16x8*)d = v;
         else for (int j = 0; j < 8 && col + j < M; ++j) d[j] = v[j];
@@ -201,15 +238,25 @@ __global__ __launch_bounds__(256) void transpose_gather_kernel(const _Float16* _
 // `scale`); dlogit itself is stored (fp32) for the weight / bias sums.
 __global__ __launch_bounds__(256) void unet_head_bwd_kernel(const float* __restrict__ dmask, const float* __restrict__ mask,
                                                             const float* __restrict__ w32, float scale, long total,
-                                                            float* __restrict__ dlogit, float* __restrict__ dy1) {
+                                                            float* __restrict__ dlogit, void* __restrict__ dy1, bool dy_f32) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
     const float m = mask[i], d = dmask[i] * m * (1.f - m);
     dlogit[i] = d;
     const float ds = d * scale;
+    if (dy_f32) {
 #pragma unroll
-    for (int c4 = 0; c4 < 8; ++c4)
-        *(float4*)(dy1 + i * 32 + c4 * 4) = make_float4(ds * w32[c4 * 4], ds * w32[c4 * 4 + 1], ds * w32[c4 * 4 + 2], ds * w32[c4 * 4 + 3]);
+        for (int c4 = 0; c4 < 8; ++c4)
+            *(float4*)((float*)dy1 + i * 32 + c4 * 4) = make_float4(ds * w32[c4 * 4], ds * w32[c4 * 4 + 1], ds * w32[c4 * 4 + 2], ds * w32[c4 * 4 + 3]);
+    } else {
+#pragma unroll
+        for (int c8 = 0; c8 < 4; ++c8) {
+            f16x8 v;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (_Float16)(ds * w32[c8 * 8 + j]);
+            *(f16x8*)((_Float16*)dy1 + i * 32 + c8 * 8) = v;
+        }
+    }
 }
 
 // weight / bias gradient of the 1x1 mask head: dw[c] = sum_i dlogit[i] * y1[i][c] (c < 32), dw[32] = sum_i dlogit[i].
@@ -312,6 +359,22 @@ extern "C" int advh_bn_stats(const void* z, const advh_map_geom* g, float* parti
     return ADVH_LAUNCH_CHECK();
 }
 
+extern "C" int advh_bn_coef(const float* sums, const float* gamma, const float* beta, int C, float n, float eps, float momentum,
+                            float* running_mean, float* running_var, int64_t* num_batches_tracked, float* coef, advh_stream_t stream) {
+    if (!sums || !gamma || !beta || !coef || C <= 0 || n <= 0.f || (!running_mean) != (!running_var)) return ADVH_EINVAL;
+    hipLaunchKernelGGL(bn_coef_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, gamma, beta, C, n, eps, momentum,
+                       running_mean, running_var, (long*)num_batches_tracked, coef);
+    return ADVH_LAUNCH_CHECK();
+}
+
+extern "C" int advh_bn_bwd_coef(const float* sums, const float* coef, int C, float n, float inv_scale, float* coef_b, float* dgamma,
+                                float* dbeta, advh_stream_t stream) {
+    if (!sums || !coef || !coef_b || !dgamma || !dbeta || C <= 0 || n <= 0.f) return ADVH_EINVAL;
+    hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, coef, C, n, inv_scale, coef_b,
+                       dgamma, dbeta);
+    return ADVH_LAUNCH_CHECK();
+}
+
 extern "C" int advh_bn_apply(const void* z, const advh_map_geom* g, const float* coef, float slope, void* a, advh_stream_t stream) {
     if (!z || !a || !coef || !geom_ok(g)) return ADVH_EINVAL;
     MapGeom m = mk(g);
@@ -365,9 +428,9 @@ extern "C" int advh_transpose_gather(const void* src, void* dst, const advh_tran
 }
 
 extern "C" int advh_unet_head_bwd(const float* dmask, const float* mask, const float* w32, float scale, int64_t total,
-                                  float* dlogit, void* dy1, advh_stream_t stream) {
+                                  float* dlogit, void* dy1, int dy_f32, advh_stream_t stream) {
     if (!dmask || !mask || !w32 || !dlogit || !dy1 || total <= 0) return ADVH_EINVAL;
     hipLaunchKernelGGL(unet_head_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dmask,
-                       mask, w32, scale, (long)total, dlogit, (float*)dy1);
+                       mask, w32, scale, (long)total, dlogit, dy1, dy_f32 != 0);
     return ADVH_LAUNCH_CHECK();
 }
