@@ -124,3 +124,46 @@ def test_training_loop_smoke(gpu_device, tiny_runtime):
             vals.append(total.item())
     assert all(np.isfinite(vals)) and any(p.grad is not None and p.grad.abs().sum() > 0 for p in net.parameters())
     print("loss per step", vals)
+
+
+def _ddp_gpu_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ["ADDVISOR_EMBEDDER"] = "tiny"
+    dist.init_process_group("gloo", rank=rank, world_size=world)       # one GPU here: the exchange is rehearsed over gloo
+    import addvisor
+    import loss_function
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    net = addvisor.UNet().to(dev)
+    net.train()
+    ddp = DDP(net)
+    loss = loss_function.LMACLoss().to(dev)
+    w = syn.make_clips(2, 80000, seed=500 + rank)                      # different clips per rank (utterance sharding)
+    _, mag, ph = loss_function.audio_processor.compute_stft(w)
+    T4 = 4 * (mag.shape[2] // 4)
+    with torch.enable_grad():
+        mask = ddp(mag[:, :512, :T4].unsqueeze(1).contiguous())
+        total, _, _ = loss.loss_function(mask, mag, ph, torch.tensor([[0.8], [0.3]]))
+        total.backward()
+    flat = torch.cat([p.grad.reshape(-1) for p in net.parameters()]).cpu()
+    gathered = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    q.put((rank, bool(torch.isfinite(flat).all()) and bool(flat.abs().sum() > 0) and all(torch.equal(g, gathered[0]) for g in gathered)))
+    dist.destroy_process_group()
+
+
+def test_data_parallel_training_step_two_ranks(gpu_device):
+    """Data-parallel training step (train_addvisor.py:410-412): two ranks, one process each, different utterances; the
+    U-Net gradients produced by the HIP backward are averaged by DistributedDataParallel (RCCL on a multi-GPU node;
+    gloo here because both ranks share the one GPU of the test box) and end up identical on both ranks."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_ddp_gpu_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = [q.get(timeout=600) for _ in procs]
+    [p.join(120) for p in procs]
+    assert all(ok for _, ok in res) and all(p.exitcode == 0 for p in procs)
