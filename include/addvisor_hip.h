@@ -159,6 +159,9 @@ typedef struct advh_gemm_desc {
     /* row pitch of W in elements; 0 = Ktot.  Lets a launch (or grid-z batch) reduce over a K-slice of a wider
        K-major matrix: the split-K weight-gradient GEMMs of the U-Net training step.                       */
     int64_t w_ld;
+    /* super-column width in N tiles for the 256-thread kernels' tile order (0 = plain row-major order): all M tiles of
+       `sc` N-tiles are walked before the next `sc`, keeping that weight slice L2-resident.                     */
+    int32_t sc;
 } advh_gemm_desc;
 
 int advh_gemm_f16(const advh_gemm_desc* desc, int tile, advh_stream_t stream);

@@ -54,7 +54,7 @@ class GemmDesc(C.Structure):
         ("n_div", C.c_int32), ("nz", C.c_int32), ("act", C.c_int32), ("slope", C.c_float),
         ("resid_f32", C.c_int32), ("ktab_identity", C.c_int32),
         ("out_h2", C.c_void_p), ("slope2", C.c_float), ("ph_r", C.c_int32), ("ph_pad", C.c_int32), ("ph_T", C.c_int32),
-        ("out_pre", C.c_void_p), ("dact_src", C.c_void_p), ("wide", C.c_int32), ("w_ld", C.c_int64),
+        ("out_pre", C.c_void_p), ("dact_src", C.c_void_p), ("wide", C.c_int32), ("w_ld", C.c_int64), ("sc", C.c_int32),
     ]
 
 
@@ -98,6 +98,21 @@ TUNER = _Tuner()
 
 def round_up(x: int, m: int) -> int:
     return (x + m - 1) // m * m
+
+
+SUPER_COLUMN_BYTES = int(os.environ.get("ADDVISOR_GEMM_SC_BYTES", "1600000"))   # +5-8 % on isolated QKV / FFN1 launches, +0.7 % in the pipeline
+
+
+def super_columns(N: int, Kp: int, M: int) -> int:
+    """Super-column width (in 128-column tiles) of the tile order: keep the weight slice in flight under
+    ``SUPER_COLUMN_BYTES`` when the whole weight would not stay resident in an XCD's 4 MiB L2; 0 = off."""
+    if SUPER_COLUMN_BYTES <= 0 or N <= 128:
+        return 0
+    tiles_n = (N + 127) // 128
+    if tiles_n * 128 * Kp * 2 <= 3 * 1024 * 1024:
+        return 0
+    sc = min(tiles_n, SUPER_COLUMN_BYTES // (128 * Kp * 2))
+    return sc if sc >= 4 else 0            # narrower super-columns re-read the activations too often (deep-K layers)
 
 
 def pick_tile(N: int, M: int = 0) -> Tuple[int, int]:
@@ -190,6 +205,7 @@ class GemmPlan:
         d.slope2 = slope2
         d.ph_r, d.ph_pad, d.ph_T = phase
         d.ktab_identity = int(bool((kt == np.arange(len(kt))).all()))
+        d.sc = super_columns(N, Kp, M)
         self.desc = d
         self.nsrc = len(sources)
         self.flops = 2.0 * M * N * K * nz          # algorithmic (unpadded) FLOPs of this launch

@@ -194,7 +194,16 @@ __global__ __launch_bounds__(64 * WM * WN, WPE) void gemm_f16_kernel(const advh_
         const int q8 = nwg / 8, r8 = nwg % 8, xcd = id % 8;
         id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + id / 8;
     }
-    const int tile_n = id % tilesN, tile_m = id / tilesN;
+    // super-columns: walk all M tiles of `sc` N-tiles before moving on, so the weight slice in flight (sc*BN*K*2
+    // bytes) stays L2-resident instead of cycling a > 4 MiB weight through every XCD's L2 (host picks sc; 0 = off)
+    int tile_n, tile_m;
+    {
+        const int tilesM = nwg / tilesN, sc = (p.sc > 0 && p.sc < tilesN) ? p.sc : tilesN;
+        const int s = id / (tilesM * sc), rem = id - s * tilesM * sc;
+        const int wcols = min(sc, tilesN - s * sc);
+        tile_m = rem / wcols;
+        tile_n = s * sc + rem - tile_m * wcols;
+    }
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int z = blockIdx.z;
 
