@@ -81,3 +81,29 @@ def test_full_batch_properties(gpu_device):
     sub = pipe.explain(w[8:24].contiguous())
     assert torch.equal(sub["theta_out"], out["theta_out"][8:24])
     assert torch.equal(sub["predictions"], out["predictions"][8:24])
+
+
+def test_explain_with_vocoder_resynthesis(gpu_device):
+    """The "masked spectrogram -> HiFi-GAN vocoder -> classifier re-forward" variant: the mask-in / mask-out clips are
+    re-rendered through the mel front end (hifigan.py:163-178) and the V1 generator before the classifier."""
+    from addvisor_hip.hifigan import HipHifigan
+    from oracle import hifigan_ref, signal_ref, wav2vec2_ref
+    cfg, hcfg = syn.tiny_config(False), syn.hifigan_tiny_config()
+    emb_sd, unet_sd, hsd = syn.embedder_weights(cfg), syn.unet_weights(), syn.hifigan_weights(hcfg)
+    coef, icpt = syn.logreg_weights(cfg.hidden_size)
+    w = syn.make_clips(2, 16000, seed=78)
+    plain = P.ExplainPipeline(cfg, emb_sd, coef, icpt, unet_sd, gpu_device, audio_length=1)
+    base = plain.explain(w.to(gpu_device), keep=True)
+    # the tiny generator takes 16 mel bands: use the first 16 rows of the 80-band mel on both sides
+    class Voc16(HipHifigan):
+        def decode_batch(self, mel):
+            return super().decode_batch(mel[:, :16].contiguous())
+    pipe = P.ExplainPipeline(cfg, emb_sd, coef, icpt, unet_sd, gpu_device, audio_length=1, vocoder=Voc16(hcfg, hsd, gpu_device))
+    out = pipe.explain(w.to(gpu_device), keep=True)
+    assert torch.equal(out["predictions"], base["predictions"]) and torch.equal(out["mask"], base["mask"])
+    for key, prob in (("wave_in", "theta_out"), ("wave_out", "masked_predictions")):
+        pre = base[key].cpu()                                                        # the ISTFT resynthesis (parity: test above)
+        voc = hifigan_ref.generator(signal_ref.mel_spectrogram(pre)[:, :16], hsd, hcfg)[:, 0, :16000]
+        assert (out[key].cpu() - voc).abs().max().item() <= 2e-2                     # tests/test_gpu_hifigan.py tolerance
+        _, p_ref = wav2vec2_ref.classify(voc, emb_sd, cfg, coef, icpt)
+        assert (out[prob].cpu() - p_ref).abs().max().item() <= TOL_PROB

@@ -26,8 +26,12 @@ METRIC_NAMES = ("faithfulness", "fidelity", "AD", "AI", "AG")
 class ExplainPipeline:
     def __init__(self, emb_cfg: EmbedderConfig, emb_sd, coef, intercept, unet_sd, device,
                  audio_length: float = 4, sampling_rate: int = 16000, domain: str = "log1p",
-                 hop: int = 322, win: int = 644, streams: int = 1):
+                 hop: int = 322, win: int = 644, streams: int = 1, vocoder=None):
+        """``vocoder``: an ``addvisor_hip.hifigan.HipHifigan``; when given, the mask-in / mask-out resyntheses are
+        re-rendered by the vocoder (mel front end of hifigan.py:163-178 -> HiFi-GAN V1 -> crop to the clip length)
+        before the classifier re-forward -- the "masked spectrogram -> vocoder -> classifier" variant of the path."""
         self.dev = device
+        self.vocoder = vocoder
         self.L = int(audio_length * sampling_rate)
         self.hop, self.win, self.domain = hop, win, domain
         self.embedder = HipEmbedder(emb_cfg, emb_sd, coef, intercept, device)
@@ -55,6 +59,11 @@ class ExplainPipeline:
             {"linear": 1, "log1p": 2}[self.domain], allw[B:].data_ptr(), allw[2 * B:].data_ptr(), L, B, mag.shape[2], L,
             self.hop, self.win, None, torch.cuda.current_stream().cuda_stream)
         _lib.check(rc, "advh_istft_masked")
+        if self.vocoder is not None:
+            voc = self.vocoder.decode_batch(ops.mel_spectrogram(allw[B:]))[:, 0]        # [2B, 256 * (1 + L // 256)]
+            k = min(L, voc.shape[1])
+            allw[B:, :k].copy_(voc[:, :k])
+            allw[B:, k:].zero_()
         if self.nstreams == 1 or (3 * B) % self.nstreams:
             _, _, p3 = self.embedder.forward(allw, L, want_hidden=False)
         else:
