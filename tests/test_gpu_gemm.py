@@ -144,3 +144,44 @@ def test_conv1d_line_tile(gpu_device, Cn, k, d, B, T):
     o3 = torch.empty_like(o1)
     ref_gemm.run(xd, out_h=o3, resid=rd)
     close(o1, o3.cpu())
+
+
+@pytest.mark.parametrize("tile", [G.TILE_256x128_PERSIST, G.TILE_256x128, G.TILE_256x256, G.TILE_128x256_W8, G.TILE_256x128_W8])
+def test_alternative_tiles_are_bit_identical(gpu_device, tile):
+    """Every tile variant walks K in the same order with fp32 accumulators, so all of them must reproduce the default
+    128x128 tile bit for bit -- on a plain GEMM with M / N tails, a gathered Conv2d with two sources, and a grid-z
+    batched ConvTranspose2d (the persistent kernel folds grid z and many tiles per workgroup into one K-step stream)."""
+    _lib.init()
+    g = torch.Generator().manual_seed(tile)
+    dev = gpu_device
+    # (1) linear: M = 70000 rows (M tail, > 256 tiles so persistent workgroups take several), N = 384, K = 192 (3 K-steps)
+    M, K, N = 70000, 192, 384
+    a = rnd(g, M + 1024, K).half().to(dev)
+    p = G.plan_linear(M, rnd(g, N, K) / K ** 0.5, rnd(g, N), act="gelu", device=dev)
+    o1, o2 = torch.empty(M, N, dtype=torch.float16, device=dev), torch.zeros(M, N, dtype=torch.float16, device=dev)
+    r = rnd(g, M, N).to(dev)
+    p.run(a, out_h=o1, resid=r)
+    p.tile = tile
+    p.run(a, out_h=o2, resid=r)
+    assert torch.equal(o1, o2)
+    # (2) conv2d, two concatenated sources, halo rows written as zeros
+    B, H, W = 3, 40, 36
+    s0, s1 = G.FMap(B, H, W, 64, 1, 1).alloc(dev), G.FMap(B, H, W, 32, 1, 1).alloc(dev)
+    s0.interior()[:] = rnd(g, B, H, W, 64).half().to(dev)
+    s1.interior()[:] = rnd(g, B, H, W, 32).half().to(dev)
+    d1, d2 = G.FMap(B, H, W, 128, 2, 2).alloc(dev), G.FMap(B, H, W, 128, 2, 2).alloc(dev)
+    pc = G.plan_conv2d([s0, s1], d1, rnd(g, 128, 96, 3, 3) * 0.05, rnd(g, 128), device=dev)
+    pc.run(s0.t, s1.t, out_h=d1.t)
+    pc.tile = tile
+    d2.t.fill_(float("nan"))
+    pc.run(s0.t, s1.t, out_h=d2.t)
+    assert torch.equal(d1.t, d2.t)
+    # (3) ConvTranspose2d kernel = stride (2, 2): grid z = 2, pixel-shuffle store
+    src = G.FMap(B, 20, 18, 128, 1, 1).alloc(dev)
+    src.interior()[:] = rnd(g, B, 20, 18, 128).half().to(dev)
+    u1, u2 = G.FMap(B, 40, 36, 128, 1, 1).alloc(dev), G.FMap(B, 40, 36, 128, 1, 1).alloc(dev)
+    pt = G.plan_convT2d(src, u1, rnd(g, 128, 128, 2, 2) * 0.05, rnd(g, 128), stride=(2, 2), device=dev)
+    pt.run(src.t, out_h=u1.t)
+    pt.tile = tile
+    pt.run(src.t, out_h=u2.t)
+    assert torch.equal(u1.t, u2.t)
