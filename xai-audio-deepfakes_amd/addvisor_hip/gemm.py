@@ -100,6 +100,7 @@ def round_up(x: int, m: int) -> int:
     return (x + m - 1) // m * m
 
 
+W8_RULE = int(os.environ.get("ADDVISOR_GEMM_W8_MIN_M", "0"))
 SUPER_COLUMN_BYTES = int(os.environ.get("ADDVISOR_GEMM_SC_BYTES", "1600000"))   # +5-8 % on isolated QKV / FFN1 launches, +0.7 % in the pipeline
 
 
@@ -156,6 +157,8 @@ class GemmPlan:
         # 16-byte epilogue stores need 8 consecutive channels per lane (permuted weight rows) and 8-aligned addressing
         wide = WIDE_EPILOGUE and N % 8 == 0 and n_div_v % 8 == 0 and all(int(x) % 8 == 0 for x in (*out, o_sNhi, o_sZ))
         tile, BN = pick_tile(N, M)
+        if W8_RULE and N % 256 == 0 and M >= W8_RULE and bool((np.asarray(ktab) == np.arange(len(ktab))).all()):
+            tile, BN = TILE_128x256_W8, 256                    # experiment switch: plain wide GEMMs on the 512-thread tile
         w_rows = round_up(N, 256)        # any tile's BN divides 256: the tile can be re-chosen later (autotune)
         store, ckey = cache if cache is not None else (None, None)
         hit = store.get(ckey) if store is not None else None

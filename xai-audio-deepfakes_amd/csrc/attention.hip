@@ -22,7 +22,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // D = head dim rounded up to a multiple of 32 (MFMA k step); dm = the real head dim (a multiple of 8): chunks beyond
 // it are zero-filled on load and skipped on store (XLS-R-2B: 1920 / 16 heads = 120 -> D = 128).
 template <int NT, int D>
-__global__ __launch_bounds__(256) void attention_kernel(const _Float16* __restrict__ qkv, _Float16* __restrict__ ctx,
+__global__ __launch_bounds__(256, (D <= 64 ? 2 : 1)) void attention_kernel(const _Float16* __restrict__ qkv, _Float16* __restrict__ ctx,
                                                         int T, int H, int dm, float scale) {
     constexpr int NKEY = NT * 16, CH = D / 8, VP = NKEY + 64 /* row pitch incl. the per-8-rows skew that spreads the transposing stores over the banks */, NS = (NT + 1) / 2, KK = D / 32, DT = D / 16;
     __shared__ __attribute__((aligned(16))) _Float16 Ks[NKEY * D];
@@ -34,16 +34,27 @@ __global__ __launch_bounds__(256) void attention_kernel(const _Float16* __restri
     const int chm = dm / 8;                          // real 16-byte chunks per row
 
     // ---- stage K (row-major, 16-byte chunks XOR-swizzled by row) and V^T; keys >= T are zero
-    for (int i = tid; i < NKEY * CH; i += 256) {
-        int key = i / CH, c = i % CH;
-        f16x8 kv = {0, 0, 0, 0, 0, 0, 0, 0}, vv = kv;
-        if (key < T && c < chm) {
-            kv = *(const f16x8*)(base + (long)key * ld + H + c * 8);
-            vv = *(const f16x8*)(base + (long)key * ld + 2 * H + c * 8);
-        }
-        *(f16x8*)(Ks + key * D + ((c ^ (key & (CH - 1))) * 8)) = kv;
+    // all global loads of this thread are issued before the first LDS store: one memory latency per workgroup instead
+    // of one per loop iteration (the transposing stores are scalar and would otherwise serialise behind each load)
+    constexpr int NIT = (NKEY * CH + 255) / 256;
+    f16x8 kreg[NIT], vreg[NIT];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) Vt[(c * 8 + j) * VP + (c & 7) * 8 + key] = vv[j];
+    for (int it = 0; it < NIT; ++it) {
+        const int i = tid + it * 256, key = i / CH, c = i % CH;
+        kreg[it] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        vreg[it] = kreg[it];
+        if (i < NKEY * CH && key < T && c < chm) {
+            kreg[it] = *(const f16x8*)(base + (long)key * ld + H + c * 8);
+            vreg[it] = *(const f16x8*)(base + (long)key * ld + 2 * H + c * 8);
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int i = tid + it * 256, key = i / CH, c = i % CH;
+        if (i >= NKEY * CH) break;
+        *(f16x8*)(Ks + key * D + ((c ^ (key & (CH - 1))) * 8)) = kreg[it];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) Vt[(c * 8 + j) * VP + (c & 7) * 8 + key] = vreg[it][j];
     }
     __syncthreads();
 
@@ -67,6 +78,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const _Float16* __restri
                 f16x8 kf = *(const f16x8*)(Ks + key * D + ((c ^ (key & (CH - 1))) * 8));
                 s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[kk], s[kt], 0, 0, 0);
             }
+            if ((kt & 1) == 1) __builtin_amdgcn_sched_barrier(0);       // keep the K-fragment reads from being hoisted en bloc (VGPR pressure)
         }
         float mx = -INFINITY;
 #pragma unroll
@@ -112,6 +124,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const _Float16* __restri
                 f16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                 o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[ss], o[dt], 0, 0, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (qrow < T) {
 #pragma unroll

@@ -202,6 +202,7 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const _Float16* __re
                 s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[kk], s[kt], 0, 0, 0);      // S^T  [key][q]
                 dp[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, of[kk], dp[kt], 0, 0, 0);    // dP^T [key][q]
             }
+            __builtin_amdgcn_sched_barrier(0);            // keeps the fragment reads of all NT tiles from being hoisted en bloc (VGPRs)
         }
         float mx = -INFINITY;
 #pragma unroll
@@ -254,6 +255,7 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const _Float16* __re
                 f16x8 kf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                 o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, dsf[ss], o[dt], 0, 0, 0);     // dQ^T [d][q]
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (qrow < T) {
 #pragma unroll
@@ -332,6 +334,7 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const _Float16* __re
                 dvt[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(oa, pf, dvt[dt], 0, 0, 0);      // dV^T [d][key]
                 dkt[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qa, dsf, dkt[dt], 0, 0, 0);     // dK^T [d][key]
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (krow < T) {
 #pragma unroll
