@@ -305,11 +305,12 @@ static int launch(const advh_gemm_desc& d, hipStream_t s) {
 // tile t; one barrier per K-step.  Wave tile (BM/WM) x (BN/WN) = 128 x 64 for 256 x 256: 24 ds_read_b128
 // feed 64 MFMAs (the 128 x 128 kernel needs 16 per 32), which is what lifts the LDS-read bound.
 template <int BM, int BN, int WM, int WN, int STAGES>
-__global__ __launch_bounds__(512) void gemm_f16_pipe_kernel(const advh_gemm_desc p) {
+__global__ __launch_bounds__(64 * WM * WN) void gemm_f16_pipe_kernel(const advh_gemm_desc p) {
     constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 16, NI = TN / 16;
-    constexpr int NA = BM / 64, NB = BN / 64;      // 16-byte chunks per thread per K-step (512 threads)
+    constexpr int NT = 64 * WM * WN, RPP = NT / 8;  // threads; tile rows covered by one loader pass
+    constexpr int NA = BM / RPP, NB = BN / RPP;     // 16-byte chunks per thread per K-step
     constexpr int STAGE = (BM + BN) * BK * 2;
-    static_assert(WM * WN == 8, "8 wavefronts");
+    static_assert(WM * WN == 8 || WM * WN == 4, "8 wavefronts (2 per SIMD) or 4 (one per SIMD, 128 x 128 wave tiles)");
     extern __shared__ __attribute__((aligned(16))) char dsmem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -328,7 +329,7 @@ __global__ __launch_bounds__(512) void gemm_f16_pipe_kernel(const advh_gemm_desc
     const _Float16* A1 = (const _Float16*)p.A1 + p.a_sZ[1] * z * 8;
     const _Float16* Wp = (const _Float16*)p.W + p.w_sZ * z;
 
-    const int ldrow = tid >> 3;                          // + 64*i
+    const int ldrow = tid >> 3;                          // + RPP*i
     const int q = (tid & 7) ^ (ldrow & 7);
     long safe0 = (long)p.h0 * p.a_sH[0] + (long)p.w0 * p.a_sW[0] + p.a_c0[0];
     long safe1 = (long)p.h0 * p.a_sH[1] + (long)p.w0 * p.a_sW[1] + p.a_c0[1];
@@ -336,7 +337,7 @@ __global__ __launch_bounds__(512) void gemm_f16_pipe_kernel(const advh_gemm_desc
     const RowDecomp rd(p.Wg, p.Hg);
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-        unsigned m = m0 + ldrow + 64 * i;
+        unsigned m = m0 + ldrow + RPP * i;
         unsigned w, h, b;
         rd(m, b, h, w);
         bool ok = m < (unsigned)p.M && (int)h >= p.h0 && (int)h < p.h1 && (int)w >= p.w0 && (int)w < p.w1;
@@ -347,7 +348,7 @@ __global__ __launch_bounds__(512) void gemm_f16_pipe_kernel(const advh_gemm_desc
     }
     const _Float16* wrow[NB];
 #pragma unroll
-    for (int i = 0; i < NB; ++i) wrow[i] = Wp + (long)(n0 + ldrow + 64 * i) * (p.w_ld ? p.w_ld : (long)p.Ktot) + q * 8;
+    for (int i = 0; i < NB; ++i) wrow[i] = Wp + (long)(n0 + ldrow + RPP * i) * (p.w_ld ? p.w_ld : (long)p.Ktot) + q * 8;
 
     const int fr = lane & 15, fq = lane >> 4;
     int offA[2], offB[2];
@@ -375,11 +376,11 @@ __global__ __launch_bounds__(512) void gemm_f16_pipe_kernel(const advh_gemm_desc
             const bool s1 = kq < 0;
             const unsigned ko = (unsigned)kq & 0x7fffffffu;
             const _Float16* g = (s1 ? A1 : A0) + ((unsigned long)((s1 ? rb1[i] : rb0[i]) + ko)) * 8;
-            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(g), LDS_PTR(st + (wv * 64 + 512 * i) * 16), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(g), LDS_PTR(st + (wv * 64 + NT * i) * 16), 16, 0, 0);
         } else {
             const int j = i - NA;
             __builtin_amdgcn_global_load_lds(GLOBAL_PTR(wrow[j] + kt * BK),
-                                             LDS_PTR(st + BM * BK * 2 + (wv * 64 + 512 * j) * 16), 16, 0, 0);
+                                             LDS_PTR(st + BM * BK * 2 + (wv * 64 + NT * j) * 16), 16, 0, 0);
         }
     };
     auto tile_kq = [&](int kt) { return p.ktab_identity ? kt * 8 + q : ktab[kt * 8 + q]; };
@@ -453,7 +454,7 @@ static int launch_pipe(const advh_gemm_desc& d, hipStream_t s) {
     const int tilesM = (d.M + BM - 1) / BM, tilesN = (d.N + BN - 1) / BN;
     if (tilesN * BN > d.w_rows) return ADVH_EINVAL;
     dim3 grid(tilesM * tilesN, 1, d.nz > 0 ? d.nz : 1);
-    hipLaunchKernelGGL((gemm_f16_pipe_kernel<BM, BN, WM, WN, STAGES>), grid, dim3(512), STAGES * (BM + BN) * BK * 2, s, d);
+    hipLaunchKernelGGL((gemm_f16_pipe_kernel<BM, BN, WM, WN, STAGES>), grid, dim3(64 * WM * WN), STAGES * (BM + BN) * BK * 2, s, d);
     return ADVH_LAUNCH_CHECK();
 }
 
@@ -785,6 +786,7 @@ int advh_init_rest() {
     if (hipFuncSetAttribute((const void*)gemm_f16_pipe_kernel<256, 256, 2, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, maxlds) != hipSuccess) return ADVH_ELAUNCH;
     if (hipFuncSetAttribute((const void*)gemm_f16_pipe_kernel<256, 128, 4, 2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, maxlds) != hipSuccess) return ADVH_ELAUNCH;
     if (hipFuncSetAttribute((const void*)gemm_f16_ring_kernel<256, 256, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, maxlds) != hipSuccess) return ADVH_ELAUNCH;
+    if (hipFuncSetAttribute((const void*)gemm_f16_pipe_kernel<256, 256, 2, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, maxlds) != hipSuccess) return ADVH_ELAUNCH;
     if (hipFuncSetAttribute((const void*)gemm_f16_persist_kernel<256, 128, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, maxlds) != hipSuccess) return ADVH_ELAUNCH;
     return ADVH_OK;
 }
@@ -810,6 +812,7 @@ extern "C" int advh_gemm_f16(const advh_gemm_desc* d, int tile, advh_stream_t st
         case ADVH_TILE_256x256_RING: return launch_ring<256, 256, 2, 4>(*d, s);
         case ADVH_TILE_256x128: return launch_pipe<256, 128, 4, 2, 3>(*d, s);
         case ADVH_TILE_256x128_PERSIST: return launch_persist<256, 128, 4, 2>(*d, s);
+        case ADVH_TILE_256x256_W4: return launch_pipe<256, 256, 2, 2, 2>(*d, s);
         default: return ADVH_EINVAL;
     }
 }
