@@ -804,8 +804,8 @@ extern "C" int advh_gemm_f16(const advh_gemm_desc* d, int tile, advh_stream_t st
         case ADVH_TILE_128x128: return launch<128, 128, 2, 2, 3>(*d, s);
         case ADVH_TILE_256x64: return launch<256, 64, 4, 1, 3>(*d, s);
         case ADVH_TILE_256x32: return launch<256, 32, 4, 1, 3>(*d, s);
-        case ADVH_TILE_256x128_W4: return launch<256, 128, 2, 2, 1>(*d, s);
-        case ADVH_TILE_128x256_W4: return launch<128, 256, 2, 2, 1>(*d, s);
+        case ADVH_TILE_256x128_W4: return launch<256, 128, 2, 2, 2>(*d, s);
+        case ADVH_TILE_128x256_W4: return launch<128, 256, 2, 2, 2>(*d, s);
         case ADVH_TILE_256x128_W8: return launch<256, 128, 4, 2, 3>(*d, s);
         case ADVH_TILE_128x256_W8: return launch<128, 256, 2, 4, 3>(*d, s);
         case ADVH_TILE_256x256: return launch_pipe<256, 256, 2, 4, 2>(*d, s);
