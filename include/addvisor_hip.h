@@ -300,6 +300,8 @@ typedef struct advh_taps_desc {
     int toff[16];
     int act;              /* ADVH_ACT_NONE | ADVH_ACT_LEAKY */
     float slope, slope2;
+    int pre_act;          /* 1: LeakyReLU(pre_slope) is applied to X inside the line buffer (X is the raw map) */
+    float pre_slope;
 } advh_taps_desc;
 int advh_conv_taps_tile(int C, int ntap, int span);       /* positions per workgroup tile (128/192/256); 0 = does not fit */
 int advh_conv_taps_lds_bytes(int C, int ntap, int span);  /* weights + two line buffers; -1 = does not fit           */

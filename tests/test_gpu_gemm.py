@@ -130,7 +130,8 @@ def test_conv1d_line_tile(gpu_device, Cn, k, d, B, T):
     src.interior()[:] = rnd(g, B, T, Cn).half()
     w, b = rnd(g, Cn, Cn, k) / (Cn * k) ** 0.5, rnd(g, Cn)
     res = rnd(g, B, src.P, Cn).half()
-    p = G.plan_conv1d_taps(src, dst, w, b, dilation=d, act="leaky", slope=0.1, slope2=0.2, device=gpu_device)
+    pre = 0.3 if (k + d) % 2 else None                                      # LeakyReLU inside the line buffer on some cases
+    p = G.plan_conv1d_taps(src, dst, w, b, dilation=d, act="leaky", slope=0.1, slope2=0.2, device=gpu_device, pre_slope=pre)
     xd, rd = src.t.to(gpu_device), res.to(gpu_device)
     o1 = torch.full((B, dst.P, Cn), float("nan"), dtype=torch.float16, device=gpu_device)
     o2 = torch.full_like(o1, float("nan"))
@@ -140,10 +141,11 @@ def test_conv1d_line_tile(gpu_device, Cn, k, d, B, T):
     close(o1, ref)
     close(o2, F.leaky_relu(ref, 0.2))
     assert (o1[:, :32] == 0).all() and (o1[:, 32 + T:] == 0).all()
-    ref_gemm = G.plan_conv1d_same(src, dst, w, b, dilation=d, act="leaky", slope=0.1, slope2=0.2, device=gpu_device)
-    o3 = torch.empty_like(o1)
-    ref_gemm.run(xd, out_h=o3, resid=rd)
-    close(o1, o3.cpu())
+    if pre is None:
+        ref_gemm = G.plan_conv1d_same(src, dst, w, b, dilation=d, act="leaky", slope=0.1, slope2=0.2, device=gpu_device)
+        o3 = torch.empty_like(o1)
+        ref_gemm.run(xd, out_h=o3, resid=rd)
+        close(o1, o3.cpu())
 
 
 @pytest.mark.parametrize("tile", [G.TILE_256x128_PERSIST, G.TILE_256x128, G.TILE_256x256, G.TILE_128x256_W8, G.TILE_256x128_W8, G.TILE_256x256_W4])

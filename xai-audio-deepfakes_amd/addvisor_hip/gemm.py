@@ -506,7 +506,7 @@ class TapsDesc(C.Structure):
                 ("out_h", C.c_void_p), ("out_h2", C.c_void_p),
                 ("M", C.c_int), ("Hg", C.c_int), ("Wg", C.c_int), ("h0", C.c_int), ("h1", C.c_int),
                 ("w0", C.c_int), ("w1", C.c_int), ("ntap", C.c_int), ("toff", C.c_int * 16),
-                ("act", C.c_int), ("slope", C.c_float), ("slope2", C.c_float)]
+                ("act", C.c_int), ("slope", C.c_float), ("slope2", C.c_float), ("pre_act", C.c_int), ("pre_slope", C.c_float)]
 
 
 TAPS_MAX_LDS = 160 * 1024
@@ -533,7 +533,7 @@ class TapsPlan:
 
     def __init__(self, *, M: int, Cn: int, w_taps: torch.Tensor, toff: Sequence[int], Hg: int, Wg: int,
                  window: Tuple[int, int, int, int], bias: Optional[torch.Tensor], act: str = "none",
-                 slope: float = 0.0, slope2: float = 0.0, device=None):
+                 slope: float = 0.0, slope2: float = 0.0, device=None, pre_slope: Optional[float] = None):
         ntap = len(toff)
         assert w_taps.shape == (ntap, Cn, Cn) and Cn in (32, 64) and 0 < ntap <= 16
         assert taps_tile(Cn, ntap, max(max(toff), 0) - min(min(toff), 0)) > 0
@@ -550,6 +550,7 @@ class TapsPlan:
         for i, t in enumerate(toff):
             d.toff[i] = int(t)
         d.act, d.slope, d.slope2 = ACT[act], slope, slope2
+        d.pre_act, d.pre_slope = int(pre_slope is not None), float(pre_slope or 0.0)
         self.desc = d
         valid = (window[1] - window[0]) * (window[3] - window[2]) * (M // (Hg * Wg))
         self.flops = 2.0 * valid * Cn * Cn * ntap
@@ -576,15 +577,17 @@ def taps_supported(src: Map1D, dst: Map1D, weight: torch.Tensor, dilation: int) 
 
 
 def plan_conv1d_taps(src: Map1D, dst: Map1D, weight: torch.Tensor, bias: Optional[torch.Tensor], *, dilation: int = 1,
-                     act: str = "none", slope: float = 0.0, slope2: float = 0.0, device=None) -> TapsPlan:
-    """Same layer as :func:`plan_conv1d_same`, on the weights-in-LDS kernel (C_in = C_out in {32, 64})."""
+                     act: str = "none", slope: float = 0.0, slope2: float = 0.0, device=None,
+                     pre_slope: Optional[float] = None) -> TapsPlan:
+    """Same layer as :func:`plan_conv1d_same`, on the weights-in-LDS kernel (C_in = C_out in {32, 64}).  With
+    ``pre_slope`` the input map is the RAW map and LeakyReLU(pre_slope) is applied inside the line buffer."""
     Cout, Cin, k = weight.shape
     pad = (k - 1) * dilation // 2
     assert taps_supported(src, dst, weight, dilation) and src.halo >= pad and (src.B, src.T) == (dst.B, dst.T)
     toff = [j * dilation - pad for j in range(k)]
     return TapsPlan(M=dst.B * dst.P, Cn=Cin, w_taps=weight.permute(2, 0, 1).float(), toff=toff, Hg=1, Wg=dst.P,
                     window=(0, 1, dst.halo, dst.halo + dst.T), bias=bias, act=act, slope=slope, slope2=slope2,
-                    device=device)
+                    device=device, pre_slope=pre_slope)
 
 
 def replay_taps_on_cpu(plan: TapsPlan, X: torch.Tensor, resid: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -596,6 +599,8 @@ def replay_taps_on_cpu(plan: TapsPlan, X: torch.Tensor, resid: Optional[torch.Te
     rows = np.arange(d.M)
     w_, h_ = rows % d.Wg, (rows // d.Wg) % d.Hg
     ok = (h_ >= d.h0) & (h_ < d.h1) & (w_ >= d.w0) & (w_ < d.w1)
+    if d.pre_act:
+        x = np.where(x > 0, x, np.float32(np.float16(d.pre_slope)) * x).astype(np.float16).astype(np.float32)
     for t in range(d.ntap):
         src = np.clip(rows + d.toff[t], 0, d.M - 1)
         out += x[src] @ W[t].T

@@ -46,6 +46,8 @@ class HipHifigan:
         def conv(src, dst, w, b, **kw):
             if self.line_tile and G.taps_supported(src, dst, w, kw.get("dilation", 1)):
                 return G.plan_conv1d_taps(src, dst, w, b, device=dev, **kw)
+            if kw.pop("pre_slope", None) is not None:
+                raise RuntimeError("a layer of a line-buffer-activated stage does not fit the line-tile kernel")
             return G.plan_conv1d_same(src, dst, w, b, device=dev, **kw)
 
         ch = cfg.upsample_initial_channel
@@ -58,21 +60,29 @@ class HipHifigan:
         nstage = len(cfg.upsample_rates)
         for i, r in enumerate(cfg.upsample_rates):
             co, t2 = ch // 2, t * r
-            x, lx = M(t2, co), M(t2, co)
+            # stages whose ResBlock convolutions run on the line-tile kernel apply LeakyReLU to the raw map inside the
+            # line buffer: no pre-activated copies are stored or read there
+            in_lds = self.line_tile and co in (32, 64) and all(
+                G.taps_tile(co, k, (k - 1) * max(cfg.resblock_dilations)) > 0 for k in cfg.resblock_kernel_sizes)
+            x = M(t2, co)
+            lx = None if in_lds else M(t2, co)
             steps.append(("gemm", G.plan_convT1d(cur, x, sd[f"ups.{i}.weight"], sd[f"ups.{i}.bias"], stride=r,
                                                  slope2=cfg.leaky_slope, device=dev), cur, None, x, lx))
-            tmp, pa, la, pb, lb = M(t2, co), M(t2, co), M(t2, co), M(t2, co), M(t2, co)
+            tmp, pa, pb = M(t2, co), M(t2, co), M(t2, co)
+            la, lb = (None, None) if in_lds else (M(t2, co), M(t2, co))
             outs = [M(t2, co) for _ in range(nk)]
             for j in range(nk):
                 p = f"resblocks.{i * nk + j}."
                 cx, clx = x, lx
                 for d in range(nd):
                     last = d == nd - 1
-                    steps.append(("gemm", conv(clx, tmp, sd[p + f"convs1.{d}.weight"], sd[p + f"convs1.{d}.bias"],
-                                               dilation=cfg.resblock_dilations[d], act="leaky", slope=cfg.leaky_slope),
-                                  clx, None, tmp, None))
+                    c1_src = cx if in_lds else clx
+                    steps.append(("gemm", conv(c1_src, tmp, sd[p + f"convs1.{d}.weight"], sd[p + f"convs1.{d}.bias"],
+                                               dilation=cfg.resblock_dilations[d], act="leaky", slope=cfg.leaky_slope,
+                                               **(dict(pre_slope=cfg.leaky_slope) if in_lds else {})),
+                                  c1_src, None, tmp, None))
                     ox = outs[j] if last else (pa if d % 2 == 0 else pb)
-                    ol = None if last else (la if d % 2 == 0 else lb)
+                    ol = None if (last or in_lds) else (la if d % 2 == 0 else lb)
                     steps.append(("gemm", conv(tmp, ox, sd[p + f"convs2.{d}.weight"], sd[p + f"convs2.{d}.bias"],
                                                slope2=cfg.leaky_slope), tmp, cx, ox, ol))
                     cx, clx = ox, ol

@@ -88,6 +88,19 @@ __global__ __launch_bounds__(256) void conv_taps_kernel(const advh_taps_desc p) 
         __syncthreads();                                           // buffer `buf` landed; everyone left buffer buf^1
         if (tile + (int)gridDim.x < ntiles) load_lines(tile + gridDim.x, buf ^ 1);
         const unsigned xl = lds0 + (unsigned)p.ntap * (C * C * 2) + (unsigned)buf * SRC * 16;
+        if (p.pre_act) {
+            // LeakyReLU applied to the line buffer in place: the producer then stores only the raw map (the residual
+            // path needs it anyway) instead of a second, pre-activated copy -- one map write and one map read less
+            char* xb = Xl + (size_t)buf * SRC * 16;
+            const _Float16 sl = (_Float16)p.pre_slope;
+            for (int i = tid; i < SRC; i += 256) {
+                f16x8 v = *(f16x8*)(xb + (size_t)i * 16);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = v[j] > (_Float16)0 ? v[j] : v[j] * sl;
+                *(f16x8*)(xb + (size_t)i * 16) = v;
+            }
+            __syncthreads();
+        }
 
         f32x4 acc[CT][NJ];
 #pragma unroll
