@@ -107,3 +107,21 @@ def test_explain_with_vocoder_resynthesis(gpu_device):
         assert (out[key].cpu() - voc).abs().max().item() <= 2e-2                     # tests/test_gpu_hifigan.py tolerance
         _, p_ref = wav2vec2_ref.classify(voc, emb_sd, cfg, coef, icpt)
         assert (out[prob].cpu() - p_ref).abs().max().item() <= TOL_PROB
+
+
+def test_hip_graph_replay_matches_eager(gpu_device):
+    """explain() captured into a HIP graph and replayed on new inputs is bit-identical to the eager launch sequence."""
+    cfg = syn.tiny_config(False)
+    emb_sd, unet_sd = syn.embedder_weights(cfg), syn.unet_weights()
+    coef, icpt = syn.logreg_weights(cfg.hidden_size)
+    pipe = P.ExplainPipeline(cfg, emb_sd, coef, icpt, unet_sd, gpu_device, audio_length=1)
+    pipe.capture(3)
+    for seed in (91, 92):
+        w = syn.make_clips(3, 16000, seed=seed).to(gpu_device)
+        eager = {k: v.clone() for k, v in pipe.explain(w).items()}
+        replay = pipe.explain_graphed(w)
+        torch.cuda.synchronize()
+        for k in ("predictions", "theta_out", "masked_predictions", "mask"):
+            assert torch.equal(eager[k], replay[k]), k
+    short = syn.make_clips(3, 9000, seed=93).to(gpu_device)                 # ragged input: zero-padded to the clip length
+    assert torch.equal(pipe.explain(short)["predictions"], pipe.explain_graphed(short)["predictions"])

@@ -83,6 +83,42 @@ class ExplainPipeline:
             out.update(mag=mag, phase=phase, wave_in=both[:B], wave_out=both[B:])
         return out
 
+    # ------------------------------------------------------------------ HIP graph replay (launch-bound small batches)
+    def capture(self, B: int) -> None:
+        """Record ``explain`` for batch size ``B`` into a HIP graph (``torch.cuda.CUDAGraph`` = hipGraph on ROCm).  One
+        explanation is ~150 kernel launches; for small batches (the interactive single-clip use of the reference's
+        streamlit study) the step is launch-bound and a single graph launch replaces the Python launch loop.  Every kernel
+        takes caller-owned buffers and a stream and never synchronises, so the whole step is capturable as it is."""
+        if not hasattr(self, "_graphs"):
+            self._graphs = {}
+        static_in = torch.zeros((B, self.L), dtype=torch.float32, device=self.dev)
+        cur = torch.cuda.current_stream()
+        side = torch.cuda.Stream(device=self.dev)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):                    # warm-up outside capture: workspaces, packed weights, LDS attributes
+            for _ in range(2):
+                self.explain(static_in)
+        cur.wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = self.explain(static_in)
+        self._graphs[B] = (graph, static_in, out)
+
+    def explain_graphed(self, waves: torch.Tensor) -> Dict[str, torch.Tensor]:
+        """Replay the captured step on ``waves [B, n]``; the returned tensors are the graph's static outputs (valid until
+        the next replay -- clone what must be kept)."""
+        B = waves.shape[0]
+        if B not in getattr(self, "_graphs", {}):
+            self.capture(B)
+        graph, static_in, out = self._graphs[B]
+        n = min(waves.shape[1], self.L)
+        static_in[:, :n].copy_(waves[:, :n])
+        if n < self.L:
+            static_in[:, n:].zero_()
+        graph.replay()
+        return out
+
     def tune(self, B: int):
         """Pick the fastest GEMM tile per launch by measurement, on a throw-away batch (call once, outside any
         timed region; the results of this pass are discarded)."""
