@@ -303,6 +303,20 @@ typedef struct advh_taps_desc {
     int pre_act;          /* 1: LeakyReLU(pre_slope) is applied to X inside the line buffer (X is the raw map) */
     float pre_slope;
 } advh_taps_desc;
+/* 2-D variant: 3x3 stride-1 "same" Conv2d, C_in = C_out = C in {32, 64}, on zero-haloed NHWC fp16 maps of ONE geometry
+ * [B][H+2PH][W_+2PW][C] (PH, PW >= 1) -- the second convolution of the U-Net's 32- / 64-channel ConvBlocks
+ * (addvisor.py:20-24 with BatchNorm folded).  16 x 16 output tiles with an 18 x 18 line-buffer patch; W [9][C_out][C_in]
+ * (tap = kh*3 + kw); only interior positions of out_h are written (its halo must already be zero).                */
+typedef struct advh_taps2d_desc {
+    const void* X;
+    const void* W;
+    const float* bias;
+    void* out_h;
+    int B, H, W_, PH, PW;
+    int act;              /* ADVH_ACT_NONE | ADVH_ACT_LEAKY */
+    float slope;
+} advh_taps2d_desc;
+int advh_conv_taps2d_f16(const advh_taps2d_desc* d, int C, advh_stream_t stream);
 int advh_conv_taps_tile(int C, int ntap, int span);       /* positions per workgroup tile (128/192/256); 0 = does not fit */
 int advh_conv_taps_lds_bytes(int C, int ntap, int span);  /* weights + two line buffers; -1 = does not fit           */
 int advh_conv_taps_f16(const advh_taps_desc* d, int C, advh_stream_t stream);

@@ -187,3 +187,29 @@ def test_alternative_tiles_are_bit_identical(gpu_device, tile):
     pt.tile = tile
     pt.run(src.t, out_h=u2.t)
     assert torch.equal(u1.t, u2.t)
+
+
+@pytest.mark.parametrize("Cn,B,H,W,PH,PW", [(32, 2, 37, 50, 2, 1), (64, 3, 16, 16, 1, 1), (64, 1, 70, 33, 1, 2), (32, 1, 256, 196, 1, 1)])
+def test_conv2d_line_tile(gpu_device, Cn, B, H, W, PH, PW):
+    """csrc/conv_taps.hip 2-D variant (16 x 16 tiles, 18 x 18 line-buffer patch, weights in LDS) against torch's conv2d on
+    the same fp16 operands, and bit-compatible geometry with the implicit-GEMM plan (partial edge tiles, halo untouched)."""
+    _lib.init()
+    g = torch.Generator().manual_seed(Cn + H)
+    src, dst = G.FMap(B, H, W, Cn, PH, PW).alloc(gpu_device), G.FMap(B, H, W, Cn, PH, PW).alloc(gpu_device)
+    x = rnd(g, B, Cn, H, W)
+    src.interior()[:] = x.permute(0, 2, 3, 1).half().to(gpu_device)
+    w, b = rnd(g, Cn, Cn, 3, 3) / (3 * Cn ** 0.5), rnd(g, Cn)
+    assert G.taps2d_supported([src], dst, w)
+    p = G.Taps2dPlan(src, dst, w, b, slope=0.2, device=gpu_device)
+    p.run(src.t, out_h=dst.t)
+    torch.cuda.synchronize()
+    ref = F.leaky_relu(F.conv2d(x.half().float(), w.half().float(), b, padding=1), 0.2)
+    close(dst.interior().permute(0, 3, 1, 2), ref)
+    halo = dst.t.clone()
+    halo[:, PH:PH + H, PW:PW + W] = 0
+    assert (halo == 0).all()                                                  # nothing outside the interior is written
+    d2 = G.FMap(B, H, W, Cn, PH, PW).alloc(gpu_device)
+    G.plan_conv2d([src], d2, w, b, slope=0.2, device=gpu_device).run(src.t, out_h=d2.t)
+    close(dst.t, d2.t.cpu())
+    assert not G.taps2d_supported([src], G.FMap(B, H, W, Cn, PH + 1, PW), w)
+    assert not G.taps2d_supported([src], dst, rnd(g, Cn, Cn, 3, 3), stride=(2, 2))

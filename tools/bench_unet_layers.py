@@ -24,6 +24,6 @@ for plan, srcs, dst in ws["steps"]:
     e1.record(); e1.synchronize()
     ms = e0.elapsed_time(e1) / 5
     tot += ms
-    kind = "taps" if isinstance(plan, G.TapsPlan) else G.TILE_NAMES[plan.tile]
+    kind = "taps2d" if isinstance(plan, G.Taps2dPlan) else G.TILE_NAMES[plan.tile]
     print(f"{'+'.join(srcs):8s} -> {dst:4s} {kind:9s} {ms*1e3:8.1f} us  {plan.flops/ms/1e9:7.1f} TFLOP/s  ({plan.flops/1e9:6.1f} GF)")
 print(f"total GEMM-shaped layers {tot:.3f} ms")

@@ -570,6 +570,56 @@ class TapsPlan:
         _lib.check(_lib.lib().advh_conv_taps_f16(C.byref(d), self.Cn, stream), "advh_conv_taps_f16")
 
 
+class Taps2dDesc(C.Structure):
+    """Mirror of ``advh_taps2d_desc`` (include/addvisor_hip.h)."""
+    _fields_ = [("X", C.c_void_p), ("W", C.c_void_p), ("bias", C.c_void_p), ("out_h", C.c_void_p),
+                ("B", C.c_int), ("H", C.c_int), ("W_", C.c_int), ("PH", C.c_int), ("PW", C.c_int),
+                ("act", C.c_int), ("slope", C.c_float)]
+
+
+def taps2d_supported(srcs: Sequence[FMap], dst: FMap, weight: torch.Tensor, stride=(1, 1), padding=(1, 1),
+                     dilation=(1, 1)) -> bool:
+    """3x3 stride-1 undilated "same" convolution with 32 or 64 channels in and out, one source, source and destination
+    maps of one geometry: the layers ``advh_conv_taps2d_f16`` takes."""
+    if len(srcs) != 1 or tuple(weight.shape[2:]) != (3, 3) or tuple(stride) != (1, 1) or tuple(padding) != (1, 1) \
+            or tuple(dilation) != (1, 1):
+        return False
+    s, Cn = srcs[0], weight.shape[0]
+    return (Cn in (32, 64) and weight.shape[1] == Cn and s.C == Cn and dst.C == Cn and s.PH >= 1 and s.PW >= 1
+            and (s.B, s.H, s.W, s.PH, s.PW) == (dst.B, dst.H, dst.W, dst.PH, dst.PW))
+
+
+class Taps2dPlan:
+    """One launch of ``advh_conv_taps2d_f16`` (same call shape as ``GemmPlan.run`` for the U-Net step list)."""
+
+    def __init__(self, src: FMap, dst: FMap, weight: torch.Tensor, bias: Optional[torch.Tensor], *, act: str = "leaky",
+                 slope: float = 0.2, device=None):
+        assert taps2d_supported([src], dst, weight)
+        Cn = weight.shape[0]
+        self.Cn = Cn
+        self.w = weight.permute(2, 3, 0, 1).reshape(9, Cn, Cn).to(torch.float16).contiguous()      # [kh*3+kw][co][ci]
+        self.bias = None if bias is None else bias.to(torch.float32).contiguous()
+        if device is not None:
+            self.w = self.w.to(device)
+            self.bias = None if self.bias is None else self.bias.to(device)
+        d = Taps2dDesc()
+        d.B, d.H, d.W_, d.PH, d.PW = dst.B, dst.H, dst.W, dst.PH, dst.PW
+        d.act, d.slope = ACT[act], slope
+        self.desc = d
+        self.flops = 2.0 * dst.B * dst.H * dst.W * Cn * Cn * 9
+
+    def run(self, A0: torch.Tensor, A1=None, *, out_h: torch.Tensor, stream: Optional[int] = None):
+        d = self.desc
+        n = d.B * (d.H + 2 * d.PH) * (d.W_ + 2 * d.PW) * self.Cn
+        for t in (A0, out_h):
+            assert t.dtype == torch.float16 and t.is_cuda and t.is_contiguous() and t.numel() == n
+        d.X, d.W, d.out_h = A0.data_ptr(), self.w.data_ptr(), out_h.data_ptr()
+        d.bias = self.bias.data_ptr() if self.bias is not None else None
+        if stream is None:
+            stream = torch.cuda.current_stream().cuda_stream
+        _lib.check(_lib.lib().advh_conv_taps2d_f16(C.byref(d), self.Cn, stream), "advh_conv_taps2d_f16")
+
+
 def taps_supported(src: Map1D, dst: Map1D, weight: torch.Tensor, dilation: int) -> bool:
     Cout, Cin, k = weight.shape
     return (Cout == Cin and Cin in (32, 64) and src.C == Cin and dst.C == Cout and src.halo == dst.halo and k <= 16

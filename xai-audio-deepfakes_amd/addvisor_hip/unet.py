@@ -26,9 +26,11 @@ def _fold_bn(sd, conv: str, bn: str) -> Tuple[torch.Tensor, torch.Tensor]:
 class HipUNet:
     """``forward(mag [B, F>=H, T>=W] fp32) -> mask [B, H, W] fp32`` (H % 16 == 0, W % 4 == 0)."""
 
-    def __init__(self, sd: Dict[str, torch.Tensor], device):
+    def __init__(self, sd: Dict[str, torch.Tensor], device, line_tile: bool = True):
+        """``line_tile``: run the 3x3 32- / 64-channel same-geometry layers on the weights-in-LDS kernel
+        (``advh_conv_taps2d_f16``) instead of the implicit GEMM."""
         _lib.init()
-        self.dev = device
+        self.dev, self.line_tile = device, line_tile
         self.sd = {k.replace("module.", ""): v.detach() for k, v in sd.items()}     # LMAC_metrics.py:23-25
         w, b = _fold_bn(self.sd, "e1.block.0", "e1.block.1")
         self.stem_w = w.reshape(32, 15).contiguous().to(device)
@@ -46,15 +48,15 @@ class HipUNet:
         dev, sd = self.dev, self.sd
         F = lambda h, w, c, ph, pw: G.FMap(B, h, w, c, ph, pw).alloc(dev)
         m = dict(
-            x1a=F(H // 2, W, 32, 1, 1), x1=F(H // 2, W, 32, 2, 1),
+            x1a=F(H // 2, W, 32, 2, 1), x1=F(H // 2, W, 32, 2, 1),
             x2a=F(H // 4, W, 64, 1, 1), x2=F(H // 4, W, 64, 1, 1),
             x3a=F(H // 8, W // 2, 128, 1, 1), x3=F(H // 8, W // 2, 128, 1, 1),
             x4a=F(H // 16, W // 4, 256, 1, 1), x4=F(H // 16, W // 4, 256, 2, 2),
             b1=F(H // 16, W // 4, 512, 4, 4), b2=F(H // 16, W // 4, 512, 0, 0),
             u4=F(H // 8, W // 2, 256, 1, 1), y4a=F(H // 8, W // 2, 256, 1, 1), y4=F(H // 8, W // 2, 256, 0, 0),
             u3=F(H // 4, W, 128, 1, 1), y3a=F(H // 4, W, 128, 1, 1), y3=F(H // 4, W, 128, 0, 0),
-            u2=F(H // 2, W, 64, 1, 1), y2a=F(H // 2, W, 64, 1, 1), y2=F(H // 2, W, 64, 0, 0),
-            u1=F(H, W, 40, 1, 1), y1a=F(H, W, 32, 1, 1), y1=F(H, W, 32, 0, 0),
+            u2=F(H // 2, W, 64, 1, 1), y2a=F(H // 2, W, 64, 1, 1), y2=F(H // 2, W, 64, 1, 1),
+            u1=F(H, W, 40, 1, 1), y1a=F(H, W, 32, 1, 1), y1=F(H, W, 32, 1, 1),
         )
         steps = []
 
@@ -63,7 +65,10 @@ class HipUNet:
             cin = sum(m[s].C for s in srcs)
             if cin != w.shape[1]:                              # d1: 33 real channels live in a 40-wide map
                 w = torch.cat([w, w.new_zeros(w.shape[0], cin - w.shape[1], *w.shape[2:])], 1)
-            plan = G.plan_conv2d([m[s] for s in srcs], m[dst], w, b, slope=SLOPE, device=dev, **kw)
+            if self.line_tile and G.taps2d_supported([m[s] for s in srcs], m[dst], w, **kw):
+                plan = G.Taps2dPlan(m[srcs[0]], m[dst], w, b, slope=SLOPE, device=dev)
+            else:
+                plan = G.plan_conv2d([m[s] for s in srcs], m[dst], w, b, slope=SLOPE, device=dev, **kw)
             steps.append((plan, srcs, dst))
 
         def block(srcs, mid, dst, name, **first):              # ConvBlock, addvisor.py:12-25

@@ -197,6 +197,129 @@ __global__ __launch_bounds__(256) void conv_taps_kernel(const advh_taps_desc p) 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// ---------------------------------------------------------------------------------------------------
+// 2-D variant: 3x3 stride-1 "same" Conv2d on a zero-haloed NHWC map (the 32- and 64-channel ConvBlock second
+// convolutions of the U-Net, addvisor.py:12-25), C_in = C_out = C.  A workgroup owns 16 x 16 output positions; the line
+// buffer is the 18 x 18 input patch (1.27 x over-read instead of the 2.5 x of a 1-D line tile on a 198-wide map), so a tap
+// (kh, kw) of output (ly, lx) is the patch row (ly + kh) * 18 + lx + kw: again a constant row offset.  Wavefront w owns
+// tile rows 4w .. 4w+3 (one 16-position column tile each).  Only interior positions are written; the destination's halo
+// stays as allocated (zero).
+template <int C>
+__global__ __launch_bounds__(256) void conv_taps2d_kernel(const advh_taps2d_desc p) {
+    constexpr int CH = C / 8, CT = C / 16, KS = C / 32, NJ = 4, PR = 18, SR = PR * PR;
+    constexpr int SRC = (SR * CH + 63) & ~63;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int fr = lane & 15, g = lane >> 4;
+    char* Wl = lds;
+    char* Xl = lds + 9 * C * C * 2;
+    const _Float16* Wg = (const _Float16*)p.W;
+    for (int i = tid; i < 9 * C * CH; i += 256) {
+        int row = i / CH, pos = i % CH;
+        const _Float16* src = Wg + ((long)(row / C) * C + cout_of(row % C)) * C + ((pos ^ swz<C>(row)) * 8);
+        __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src), LDS_PTR(Wl + (size_t)(i - lane) * 16), 16, 0, 0);
+    }
+    const _Float16* X = (const _Float16*)p.X;
+    const int Hp = p.H + 2 * p.PH, Wp = p.W_ + 2 * p.PW;
+    const int tx = (p.W_ + 15) / 16, ty = (p.H + 15) / 16, ntiles = p.B * ty * tx;
+    auto origin = [&](int tile, int& b, int& y0, int& x0) {
+        x0 = (tile % tx) * 16;
+        const int r = tile / tx;
+        y0 = (r % ty) * 16;
+        b = r / ty;
+    };
+    auto load_patch = [&](int tile, int buf) {
+        int b, y0, x0;
+        origin(tile, b, y0, x0);
+        char* dst = Xl + (size_t)buf * SRC * 16;
+        for (int i = tid; i < SRC; i += 256) {
+            int row = i / CH, pos = i % CH;
+            if (row >= SR) row = 0;
+            // padded coordinates of patch row `row`, clamped into the map (clamped rows only feed skipped outputs)
+            int gy = min(y0 + p.PH - 1 + row / PR, Hp - 1), gx = min(x0 + p.PW - 1 + row % PR, Wp - 1);
+            const _Float16* src = X + (((long)b * Hp + gy) * Wp + gx) * C + ((pos ^ swz<C>(i / CH)) * 8);
+            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src), LDS_PTR(dst + (size_t)(i - lane) * 16), 16, 0, 0);
+        }
+    };
+    float4 bias[CT];
+#pragma unroll
+    for (int i = 0; i < CT; ++i)
+        bias[i] = p.bias ? *(const float4*)(p.bias + (i >> 1) * 32 + g * 8 + (i & 1) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const unsigned lds0 = (unsigned)(unsigned long)LDS_PTR(lds);
+    constexpr int NS = 9 * KS;
+    int buf = 0;
+    if ((int)blockIdx.x < ntiles) load_patch(blockIdx.x, 0);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, buf ^= 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) load_patch(tile + gridDim.x, buf ^ 1);
+        const unsigned xl = lds0 + 9 * C * C * 2 + (unsigned)buf * SRC * 16;
+        f32x4 acc[CT][NJ];
+#pragma unroll
+        for (int i = 0; i < CT; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        unsigned wa_[2], xa_[2][NJ];
+        auto addr = [&](int s, unsigned& wa, unsigned (&xa)[NJ]) {
+            const int t = s / KS, c = (s % KS) * 4 + g, kh = t / 3, kw = t - kh * 3;
+            wa = lds0 + (unsigned)t * (C * C * 2) + (fr * CH + (c ^ swz<C>(fr))) * 16;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int row = (wv * NJ + j + kh) * PR + kw + fr;
+                xa[j] = xl + (row * CH + (c ^ swz<C>(row))) * 16;
+            }
+        };
+        f16x8 wf[2][CT], xf[2][NJ];
+        addr(0, wa_[0], xa_[0]);
+#pragma unroll
+        for (int i = 0; i < CT; ++i) DS_READ128(wf[0][i], wa_[0], i * 16 * C * 2);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) DS_READ128(xf[0][j], xa_[0][j], 0);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {                              // 9 taps x KS k-steps, fully unrolled: static register double buffer
+            const int cur = s & 1, nxt = cur ^ 1;
+            if (s + 1 < NS) addr(s + 1, wa_[nxt], xa_[nxt]);
+            LGKM_WAIT(0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < CT * NJ; ++m) {
+                const int i = m / NJ, j = m % NJ;
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[cur][i], xf[cur][j], acc[i][j], 0, 0, 0);
+                if (s + 1 < NS) {
+                    if (m < CT) DS_READ128(wf[nxt][m < CT ? m : 0], wa_[nxt], (m < CT ? m : 0) * 16 * C * 2);
+                    else if (m < CT + NJ) DS_READ128(xf[nxt][m - CT < NJ ? m - CT : 0], xa_[nxt][m - CT < NJ ? m - CT : 0], 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        int b, y0, x0;
+        origin(tile, b, y0, x0);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int gy = y0 + wv * NJ + j, gx = x0 + fr;
+            if (gy >= p.H || gx >= p.W_) continue;
+            const long pos = ((long)b * Hp + gy + p.PH) * Wp + gx + p.PW;
+#pragma unroll
+            for (int q = 0; q < CT / 2; ++q) {
+                const long o = pos * C + q * 32 + g * 8;
+                float v[8];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { v[r] = acc[2 * q][j][r]; v[4 + r] = acc[2 * q + 1][j][r]; }
+                v[0] += bias[2 * q].x; v[1] += bias[2 * q].y; v[2] += bias[2 * q].z; v[3] += bias[2 * q].w;
+                v[4] += bias[2 * q + 1].x; v[5] += bias[2 * q + 1].y; v[6] += bias[2 * q + 1].z; v[7] += bias[2 * q + 1].w;
+                f16x8 hv;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const float a = (p.act == ADVH_ACT_LEAKY && v[r] < 0.f) ? p.slope * v[r] : v[r];
+                    hv[r] = (_Float16)a;
+                }
+                *(f16x8*)((_Float16*)p.out_h + o) = hv;
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 static int taps_span(const advh_taps_desc* d) {
     int lo = 0, hi = 0;
     for (int t = 0; t < d->ntap; ++t) { lo = d->toff[t] < lo ? d->toff[t] : lo; hi = d->toff[t] > hi ? d->toff[t] : hi; }
@@ -245,5 +368,26 @@ extern "C" int advh_conv_taps_f16(const advh_taps_desc* d, int C, advh_stream_t 
     int grid = 256 * per_cu;
     if (grid > ntiles) grid = ntiles;
     hipLaunchKernelGGL(kerns[ci][ji], dim3(grid), dim3(256), lds, (hipStream_t)stream, *d);
+    return ADVH_LAUNCH_CHECK();
+}
+
+extern "C" int advh_conv_taps2d_f16(const advh_taps2d_desc* d, int C, advh_stream_t stream) {
+    if (!d || !d->X || !d->W || !d->out_h || d->B <= 0 || d->H <= 0 || d->W_ <= 0 || d->PH < 1 || d->PW < 1) return ADVH_EINVAL;
+    if (C != 32 && C != 64) return ADVH_EUNSUPPORTED;
+    if (d->act != ADVH_ACT_NONE && d->act != ADVH_ACT_LEAKY) return ADVH_EINVAL;
+    const int lds = 9 * C * C * 2 + 2 * ((18 * 18 * (C / 8) + 63) / 64 * 64) * 16;
+    static bool attr[2] = {false, false};
+    const int ci = C == 64;
+    const void* fn = ci ? (const void*)conv_taps2d_kernel<64> : (const void*)conv_taps2d_kernel<32>;
+    if (!attr[ci]) {
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return ADVH_ELAUNCH;
+        attr[ci] = true;
+    }
+    const long ntiles = (long)d->B * ((d->H + 15) / 16) * ((d->W_ + 15) / 16);
+    const int per_cu = lds <= 80 * 1024 ? 2 : 1;
+    long grid = 256L * per_cu;
+    if (grid > ntiles) grid = ntiles;
+    if (ci) hipLaunchKernelGGL(conv_taps2d_kernel<64>, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, *d);
+    else hipLaunchKernelGGL(conv_taps2d_kernel<32>, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, *d);
     return ADVH_LAUNCH_CHECK();
 }
