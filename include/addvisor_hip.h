@@ -164,6 +164,10 @@ typedef struct advh_gemm_desc {
     /* super-column width in N tiles for the 256-thread kernels' tile order (0 = plain row-major order): all M tiles of
        `sc` N-tiles are walked before the next `sc`, keeping that weight slice L2-resident.                     */
     int32_t sc;
+    /* second level of the column -> address split (ConvTranspose2d with all kh*kw sub-pixels in ONE launch): with
+       q = n / n_div, the offset is (q / n_sub)*o_sNhh + (q % n_sub)*o_sNhi instead of q*o_sNhi; n_sub <= 1 = off. */
+    int32_t n_sub;
+    int64_t o_sNhh;
 } advh_gemm_desc;
 
 int advh_gemm_f16(const advh_gemm_desc* desc, int tile, advh_stream_t stream);

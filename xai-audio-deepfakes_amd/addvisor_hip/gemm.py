@@ -54,7 +54,7 @@ class GemmDesc(C.Structure):
         ("n_div", C.c_int32), ("nz", C.c_int32), ("act", C.c_int32), ("slope", C.c_float),
         ("resid_f32", C.c_int32), ("ktab_identity", C.c_int32),
         ("out_h2", C.c_void_p), ("slope2", C.c_float), ("ph_r", C.c_int32), ("ph_pad", C.c_int32), ("ph_T", C.c_int32),
-        ("out_pre", C.c_void_p), ("dact_src", C.c_void_p), ("wide", C.c_int32), ("w_ld", C.c_int64), ("sc", C.c_int32),
+        ("out_pre", C.c_void_p), ("dact_src", C.c_void_p), ("wide", C.c_int32), ("w_ld", C.c_int64), ("sc", C.c_int32), ("n_sub", C.c_int32), ("o_sNhh", C.c_int64),
     ]
 
 
@@ -145,7 +145,8 @@ class GemmPlan:
                  out: Tuple[int, int, int, int], n_div: Optional[int] = None, o_sNhi: int = 0,
                  o_sZ: int = 0, nz: int = 1, bias: Optional[torch.Tensor] = None, act: str = "none",
                  slope: float = 0.0, device=None, w_sZ: Optional[int] = None, bias_sZ: int = 0,
-                 slope2: float = 0.0, phase: Tuple[int, int, int] = (0, 0, 0), cache: Optional[tuple] = None):
+                 slope2: float = 0.0, phase: Tuple[int, int, int] = (0, 0, 0), cache: Optional[tuple] = None,
+                 n_sub: int = 0, o_sNhh: int = 0):
         """``w2``: fp32 ``[nz, N, K]`` (K = 8 * len(ktab) before padding) or a zero-argument callable returning it
         (only called when the packed weight is not in ``cache``); ``ktab``: int64 chunk offsets with bit 31 as
         source selector; ``out`` = (o_sB, o_sH, o_sW, o_c0) in elements.  ``cache = (dict, key)`` shares the
@@ -155,7 +156,7 @@ class GemmPlan:
         Kp = round_up(K, BK)
         n_div_v = n_div if n_div is not None else round_up(N, 4)
         # 16-byte epilogue stores need 8 consecutive channels per lane (permuted weight rows) and 8-aligned addressing
-        wide = WIDE_EPILOGUE and N % 8 == 0 and n_div_v % 8 == 0 and all(int(x) % 8 == 0 for x in (*out, o_sNhi, o_sZ))
+        wide = WIDE_EPILOGUE and N % 8 == 0 and n_div_v % 8 == 0 and all(int(x) % 8 == 0 for x in (*out, o_sNhi, o_sZ, o_sNhh))
         tile, BN = pick_tile(N, M)
         if W8_RULE and N % 256 == 0 and M >= W8_RULE and bool((np.asarray(ktab) == np.arange(len(ktab))).all()):
             tile, BN = TILE_128x256_W8, 256                    # experiment switch: plain wide GEMMs on the 512-thread tile
@@ -201,6 +202,7 @@ class GemmPlan:
         d.bias_sZ = bias_sZ
         d.o_sB, d.o_sH, d.o_sW, d.o_c0 = out
         d.o_sNhi, d.o_sZ = o_sNhi, o_sZ
+        d.n_sub, d.o_sNhh = n_sub, o_sNhh
         d.n_div = n_div_v
         d.wide = int(wide)
         d.nz = nz
@@ -387,24 +389,26 @@ def plan_conv2d(srcs: Sequence[FMap], dst: FMap, weight: torch.Tensor, bias: Opt
 
 def plan_convT2d(src: FMap, dst: FMap, weight: torch.Tensor, bias: torch.Tensor, *, stride, dst_c0: int = 0,
                  device=None) -> GemmPlan:
-    """nn.ConvTranspose2d with kernel == stride (addvisor.py:45-54): a GEMM over the input pixels whose
-    epilogue scatters the (i, j) sub-pixels (grid z = i, column block = j).  Only ``dst``'s interior is
-    written; its halo must already be zero."""
+    """nn.ConvTranspose2d with kernel == stride (addvisor.py:45-54): a GEMM over the input pixels whose epilogue
+    scatters all kh*kw sub-pixels (column block q = i*sw + j -> row offset i, column offset j: the two-level column
+    split of the descriptor), so the input is read once.  Only ``dst``'s interior is written; its halo must already be
+    zero."""
     Cin, Cout, KH, KW = weight.shape
     sh, sw = stride
     assert (KH, KW) == (sh, sw) and src.C == Cin and Cin % 8 == 0 and Cout % 4 == 0
     assert (dst.H, dst.W) == (src.H * sh, src.W * sw)
     cc = Cin // 8
     Ct = dst.C
-    # w2[z=i][n = j*Cout + co][ci]
-    w2 = weight.permute(2, 3, 1, 0).reshape(sh, sw * Cout, Cin).float()
-    b2 = bias.float().repeat(sw)
+    # w2[n = (i*sw + j)*Cout + co][ci]
+    w2 = weight.permute(2, 3, 1, 0).reshape(1, sh * sw * Cout, Cin).float()
+    b2 = bias.float().repeat(sh * sw)
     o_c0 = ((-sh * src.PH + dst.PH) * dst.Wp + (-sw * src.PW + dst.PW)) * Ct + dst_c0
-    return GemmPlan(M=src.B * src.Hp * src.Wp, N=sw * Cout, w2=w2, ktab=np.arange(cc, dtype=np.int64),
+    return GemmPlan(M=src.B * src.Hp * src.Wp, N=sh * sw * Cout, w2=w2, ktab=np.arange(cc, dtype=np.int64),
                     sources=[Source(src.Hp * src.Wp * cc, src.Wp * cc, cc, 0)], Hg=src.Hp, Wg=src.Wp,
                     window=(src.PH, src.PH + src.H, src.PW, src.PW + src.W), halo_zero=False,
-                    out=(dst.Hp * dst.Wp * Ct, sh * dst.Wp * Ct, sw * Ct, o_c0), n_div=Cout, o_sNhi=Ct,
-                    o_sZ=dst.Wp * Ct, nz=sh, bias=b2, bias_sZ=0, act="none", device=device)
+                    out=(dst.Hp * dst.Wp * Ct, sh * dst.Wp * Ct, sw * Ct, o_c0), n_div=Cout,
+                    o_sNhi=Ct if sw > 1 else dst.Wp * Ct, n_sub=sw if sw > 1 else 0, o_sNhh=dst.Wp * Ct if sw > 1 else 0,
+                    bias=b2, bias_sZ=0, act="none", device=device)
 
 
 # ------------------------------------------------------------------------------------------ CPU replay
@@ -433,7 +437,9 @@ def replay_on_cpu(plan: GemmPlan, A0: torch.Tensor, A1: Optional[torch.Tensor], 
                 continue
             orow = b_ * d.o_sB + h_ * d.o_sH + w_ * d.o_sW + d.o_c0 + d.o_sZ * z
             cols = np.arange(d.N)
-            o = orow + (cols // d.n_div) * d.o_sNhi + cols % d.n_div
+            qn = cols // d.n_div
+            hi = (qn // d.n_sub) * d.o_sNhh + (qn % d.n_sub) * d.o_sNhi if d.n_sub > 1 else qn * d.o_sNhi
+            o = orow + hi + cols % d.n_div
             if not ok:
                 out[o] = 0.0
                 continue

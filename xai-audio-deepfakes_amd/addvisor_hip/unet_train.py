@@ -315,7 +315,7 @@ class HipUNetTrain:
             if L["kind"] == "up":
                 w = p[L["name"] + ".weight"].detach()
                 sh, sw = L["stride"]
-                L["fwd"].load_weights(w.permute(2, 3, 1, 0).reshape(sh, sw * L["Cout"], L["Cin"]), p[L["name"] + ".bias"].detach().repeat(sw))
+                L["fwd"].load_weights(w.permute(2, 3, 1, 0).reshape(1, sh * sw * L["Cout"], L["Cin"]), p[L["name"] + ".bias"].detach().repeat(sh * sw))
                 L["fwd"].run(L["src"].t, out_h=L["dst"].t)
                 continue
             dst = L["dst"]

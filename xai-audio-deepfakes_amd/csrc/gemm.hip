@@ -147,7 +147,8 @@ __device__ __forceinline__ void gemm_epilogue(const advh_gemm_desc& p, f32x4 (&a
                     int to = (int)w * p.ph_r + n / p.n_div - p.ph_pad;
                     if (to < 0 || to >= p.ph_T) continue;
                 }
-                long o = orow + (long)(n / p.n_div) * p.o_sNhi + (n % p.n_div);
+                const int qn = n / p.n_div;
+                long o = orow + (p.n_sub > 1 ? (long)(qn / p.n_sub) * p.o_sNhh + (long)(qn % p.n_sub) * p.o_sNhi : (long)qn * p.o_sNhi) + (n % p.n_div);
                 float v[8];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { v[r] = acc[2 * q][mi][r]; v[4 + r] = acc[2 * q + 1][mi][r]; }
@@ -162,7 +163,8 @@ __device__ __forceinline__ void gemm_epilogue(const advh_gemm_desc& p, f32x4 (&a
                     int to = (int)w * p.ph_r + n / p.n_div - p.ph_pad;
                     if (to < 0 || to >= p.ph_T) continue;
                 }
-                long o = orow + (long)(n / p.n_div) * p.o_sNhi + (n % p.n_div);
+                const int qn = n / p.n_div;
+                long o = orow + (p.n_sub > 1 ? (long)(qn / p.n_sub) * p.o_sNhh + (long)(qn % p.n_sub) * p.o_sNhi : (long)qn * p.o_sNhi) + (n % p.n_div);
                 float v[4] = {acc[ni][mi][0], acc[ni][mi][1], acc[ni][mi][2], acc[ni][mi][3]};
                 epilogue_store<4>(p, v, ok, bias, n, o);
             }
