@@ -11,7 +11,7 @@ obtains bit-identical metrics for any world size.
 """
 from __future__ import annotations
 
-from typing import Dict, Optional
+from typing import Dict
 
 import torch
 

@@ -26,7 +26,6 @@ import ctypes as C
 import math
 from typing import Dict, List, Optional, Tuple
 
-import numpy as np
 import torch
 
 from . import _lib, gemm as G

@@ -9,7 +9,7 @@ import torch.nn as nn
 from addvisor_hip import pipeline as _P, runtime as _rt
 from audioprocessor import AudioProcessor
 from captum.attr import InputXGradient, IntegratedGradients, Saliency  # noqa: F401
-from classifier_embedder import TorchLogReg
+from classifier_embedder import TorchLogReg  # noqa: F401  (name kept for callers of the reference module)
 
 device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
 audioprocessor = AudioProcessor()

@@ -8,7 +8,7 @@ import torch.nn.functional as F
 
 from addvisor_hip import ops as _ops, runtime as _rt
 from audioprocessor import AudioProcessor
-from classifier_embedder import TorchLogReg
+from classifier_embedder import TorchLogReg  # noqa: F401  (the reference module exposes it, loss_function.py:15)
 
 device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
 audio_processor = AudioProcessor()
