@@ -373,6 +373,19 @@ int advh_unet_head_wgrad(const float* dlogit, const void* y1, int64_t total, flo
 int advh_unet_stem_wgrad(const void* dz, int Fq, int Tq, int B, int H, int W, const float* mag, int PH, int PW,
                          float* partial, float* dw, advh_stream_t stream);
 
+/* Weight gradient of a 3x3 stride-1 "same" Conv2d, C_in = C_out = C in {32, 64}, without transposed copies in HBM:
+ * dw[kh*3+kw][co][ci] = sum_p dz[p][co] * x[p + (kh-1, kw-1)][ci].  X and DZ are zero-haloed channels-last fp16 maps of
+ * the same interior [B][H][W_] with their own halos (>= 1); both MFMA operands are read from LDS tiles with
+ * ds_read_b64_tr_b16 (k = position).  partial: advh_conv_wgrad2d_parts(C,B,H,W) * 9*C*C floats of scratch; dw: 9*C*C.  */
+typedef struct advh_wgrad2d_desc {
+    const void* X;
+    const void* DZ;
+    float* partial;
+    int B, H, W_, PHx, PWx, PHz, PWz;
+} advh_wgrad2d_desc;
+int advh_conv_wgrad2d_parts(int C, int B, int H, int W);
+int advh_conv_wgrad2d_f16(const advh_wgrad2d_desc* d, int C, float* dw, advh_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
