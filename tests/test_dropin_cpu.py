@@ -34,6 +34,12 @@ def test_modules_import_without_gpu_or_network():
     assert lm.w_raw.tolist() == [3.0, 0.5, 3.0] and torch.allclose(lm.w, torch.nn.functional.softplus(lm.w_raw))
     clf = classifier_embedder.classifier
     assert clf.coef_.shape == (1, 768) and clf.intercept_.shape == (1,)
+    import hifigan
+    import train_addvisor
+    import train_logReg_swapping
+    for name in ("extract_wavs", "AudioDataset", "collate_fn", "train_addvisor", "UNet", "LMACLoss"):
+        assert hasattr(train_addvisor, name)                        # importing runs nothing (the reference trains at import)
+    assert hasattr(hifigan, "generate_band_swap_dataset") and hasattr(train_logReg_swapping, "train_logReg_timeswap")
 
 
 def test_unet_state_dict_layout():
