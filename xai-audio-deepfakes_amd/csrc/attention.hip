@@ -137,6 +137,113 @@ __global__ __launch_bounds__(256, (D <= 64 ? 2 : 1)) void attention_kernel(const
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Head dim 64 (wav2vec2-base / -large): K and V are both staged ROW-major by the LDS DMA (no register round trip, no
+// scalar transposing stores, no V^T buffer) and the V^T operand of O^T = V^T P^T is read with the transposing LDS load
+// ds_read_b64_tr_b16: lane i of a 16-lane group receives dim d0+i of four consecutive keys, and the key order
+// (4g+q | 16+4g+q) of the two reads is exactly the order the P registers already have.  53 KB of LDS at T = 199
+// => three workgroups per CU instead of two.
+typedef __fp16 trvec __attribute__((__vector_size__(4 * sizeof(__fp16))));
+#define GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+template <int NT>
+__global__ __launch_bounds__(256, 2) void attention_tr_kernel(const _Float16* __restrict__ qkv, _Float16* __restrict__ ctx,
+                                                              int T, int H, float scale) {
+    constexpr int D = 64, NKEY = NT * 16, CH = 8, NS = (NT + 1) / 2, KK = 2, DT = 4;
+    __shared__ __attribute__((aligned(16))) _Float16 Ks[NKEY * D];
+    __shared__ __attribute__((aligned(16))) _Float16 Vs[NKEY * D];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int head = blockIdx.x, b = blockIdx.y;
+    const long ld = 3L * H;
+    const _Float16* base = qkv + (long)b * T * ld + head * D;
+    for (int i = tid; i < NKEY * CH; i += 256) {          // chunk c of key r sits at slot c ^ (r & 7); keys >= T re-read key T-1 (finite,
+        const int key = i / CH, c = (i % CH) ^ (key & 7);  // masked by the softmax / multiplied by P = 0)
+        const _Float16* src = base + (long)min(key, T - 1) * ld + c * 8;
+        __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src + H), LDS_PTR((char*)Ks + (size_t)(i - lane) * 16), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src + 2 * H), LDS_PTR((char*)Vs + (size_t)(i - lane) * 16), 16, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int fr = lane & 15, g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    const auto* vs3 = (const __attribute__((address_space(3))) char*)LDS_PTR(Vs);
+    for (int qt = wv; qt * 16 < T; qt += 4) {
+        const int qrow = qt * 16 + fr;
+        const int qr = qrow < T ? qrow : T - 1;
+        f16x8 qf[KK];
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) qf[kk] = *(const f16x8*)(base + (long)qr * ld + kk * 32 + g * 8);
+        f32x4 s[NT];
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+            s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) {
+                const int key = kt * 16 + fr, c = kk * 4 + g;
+                const f16x8 kf = *(const f16x8*)(Ks + key * D + ((c ^ (key & 7)) * 8));
+                s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[kk], s[kt], 0, 0, 0);
+            }
+            if ((kt & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = (kt * 16 + g * 4 + r < T) ? s[kt][r] * scale : -INFINITY;
+                s[kt][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const float e = expf(s[kt][r] - mx); s[kt][r] = e; sum += e; }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.f / sum;
+        f16x8 pf[NS];
+#pragma unroll
+        for (int ss = 0; ss < NS; ++ss)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                pf[ss][r] = (_Float16)(s[2 * ss][r] * inv);
+                pf[ss][4 + r] = (2 * ss + 1 < NT) ? (_Float16)(s[(2 * ss + 1 < NT) ? 2 * ss + 1 : 0][r] * inv) : (_Float16)0.f;
+            }
+        f32x4 o[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ss = 0; ss < NS; ++ss) {
+            // keys 32 ss + 4g + q (elements 0-3) and 32 ss + 16 + 4g + q (elements 4-7); a missing odd tile re-reads the even one (P = 0)
+            const int ra = 32 * ss + 4 * g + q, rb = (2 * ss + 1 < NT) ? ra + 16 : ra;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const int chn = dt * 2 + (pp >> 1), sub = (pp & 1) * 8;
+                trvec lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+                    (__attribute__((address_space(3))) trvec*)(vs3 + ((size_t)ra * CH + (chn ^ (ra & 7))) * 16 + sub));
+                trvec hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+                    (__attribute__((address_space(3))) trvec*)(vs3 + ((size_t)rb * CH + (chn ^ (rb & 7))) * 16 + sub));
+                f16x8 vf;
+                __builtin_memcpy(&vf, &lo, 8);
+                __builtin_memcpy((char*)&vf + 8, &hi, 8);
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[ss], o[dt], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (qrow < T) {
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                f16x4 hv = {(_Float16)o[dt][0], (_Float16)o[dt][1], (_Float16)o[dt][2], (_Float16)o[dt][3]};
+                *(f16x4*)(ctx + ((long)b * T + qrow) * H + head * D + dt * 16 + g * 4) = hv;
+            }
+        }
+    }
+}
+
 }  // namespace advh
 
 using namespace advh;
@@ -151,7 +258,10 @@ extern "C" int advh_attention_f16(const void* qkv, void* ctx, int B, int T, int 
     hipStream_t s = (hipStream_t)stream;
     const int nt = (T + 15) / 16;
 #define ATT(NT_, D_) hipLaunchKernelGGL((attention_kernel<NT_, D_>), grid, block, 0, s, (const _Float16*)qkv, (_Float16*)ctx, T, H, dm, scale)
-    if (D == 64) {
+#define ATT_TR(NT_) hipLaunchKernelGGL((attention_tr_kernel<NT_>), grid, block, 0, s, (const _Float16*)qkv, (_Float16*)ctx, T, H, scale)
+    if (dm == 64) {                                        // row-major staging by DMA + transposing V^T reads
+        if (nt <= 4) ATT_TR(4); else if (nt <= 8) ATT_TR(8); else if (nt <= 13) ATT_TR(13); else ATT_TR(16);
+    } else if (D == 64) {
         if (nt <= 4) ATT(4, 64); else if (nt <= 8) ATT(8, 64); else if (nt <= 13) ATT(13, 64); else ATT(16, 64);
     } else if (D == 32) {
         if (nt <= 4) ATT(4, 32); else if (nt <= 8) ATT(8, 32); else if (nt <= 13) ATT(13, 32); else ATT(16, 32);
@@ -159,5 +269,6 @@ extern "C" int advh_attention_f16(const void* qkv, void* ctx, int B, int T, int 
         if (nt <= 4) ATT(4, 128); else if (nt <= 13) ATT(13, 128); else ATT(16, 128);
     }
 #undef ATT
+#undef ATT_TR
     return ADVH_LAUNCH_CHECK();
 }
