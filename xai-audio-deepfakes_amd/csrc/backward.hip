@@ -132,15 +132,37 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
 //   B (one wavefront per 16-key tile, scores un-transposed: query on the MFMA row): recompute P and dS with the
 //     saved row statistics; dV^T = dO^T P and dK^T = Q^T dS again sum over the accumulator's row index.
 // Recomputing S and dP in both orientations costs 2x of a small op and needs no transposes or atomics.
-template <int NT, int D>
+// TR (head dim exactly 64): no transposed copies at all -- K, V (pass A) and Q, dO (pass B) are staged row-major by the
+// LDS DMA and the three operands that need the transposed orientation (K^T for dQ, dO^T for dV, Q^T for dK) are read with
+// ds_read_b64_tr_b16; the key / query order of its two 4-row reads (4g+q | 16+4g+q) is the order the dS / P registers
+// already have.  LDS drops from 88 KB to 53 KB (+ statistics).
+typedef __fp16 trvec __attribute__((__vector_size__(4 * sizeof(__fp16))));
+#define ADVH_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+#define ADVH_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+// 8 consecutive-in-k values of column (c0 + lane%16) from a row-major [rows][64] fp16 LDS tile whose 16-byte chunk c of
+// row r sits at slot c ^ (r & 7); rows ra+q (elements 0-3) and rb+q (elements 4-7)
+__device__ __forceinline__ f16x8 tr_frag64(const __attribute__((address_space(3))) char* base, int ra, int rb, int c0, int p) {
+    const int ch = (c0 >> 3) + (p >> 1), sub = (p & 1) * 8;
+    trvec lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) trvec*)(base + ((size_t)ra * 8 + (ch ^ (ra & 7))) * 16 + sub));
+    trvec hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) trvec*)(base + ((size_t)rb * 8 + (ch ^ (rb & 7))) * 16 + sub));
+    f16x8 r;
+    __builtin_memcpy(&r, &lo, 8);
+    __builtin_memcpy((char*)&r + 8, &hi, 8);
+    return r;
+}
+
+template <int NT, int D, bool TR>
 __global__ __launch_bounds__(256) void attention_bwd_kernel(const _Float16* __restrict__ qkv, const _Float16* __restrict__ dctx,
                                                             _Float16* __restrict__ dqkv, int T, int H, int dm, float scale) {
     constexpr int NKEY = NT * 16, CH = D / 8, VP = NKEY + 64, NS = (NT + 1) / 2, KK = D / 32, DT = D / 16;
-    constexpr int ROWB = NKEY * D, TRB = D * VP;
+    constexpr int ROWB = NKEY * D, TRB = TR ? 0 : D * VP;
+    static_assert(!TR || D == 64, "the transposing-read path is for head dim 64");
     // LDS: pass A uses K | V (row-major, swizzled) | Kt ; pass B re-uses the space for Qt | dOt ; stats stay.
     // For D = 128 V is not staged (pass A reads its fragments from global memory) to stay inside 160 KiB.
     constexpr bool STAGE_V = D <= 64;
-    constexpr int LDSH = (STAGE_V ? 2 * ROWB + TRB : ROWB + TRB) > 2 * TRB ? (STAGE_V ? 2 * ROWB + TRB : ROWB + TRB) : 2 * TRB;
+    constexpr int LDSH = TR ? 2 * ROWB
+                            : ((STAGE_V ? 2 * ROWB + TRB : ROWB + TRB) > 2 * TRB ? (STAGE_V ? 2 * ROWB + TRB : ROWB + TRB) : 2 * TRB);
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     _Float16* Ks = (_Float16*)smem_raw;
     _Float16* Vs = Ks + ROWB;
@@ -160,7 +182,18 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const _Float16* __re
     const int chm = dm / 8;                                        // real 16-byte chunks per row (D - dm is zero padding)
     const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
     const int fr = lane & 15, g = lane >> 4;
+    const int tq = (lane >> 2) & 3, tp = lane & 3;                 // this lane's (row, column quad) inside a transposing read
+    const auto* smem3 = (const __attribute__((address_space(3))) char*)ADVH_LDS_PTR(smem_raw);
 
+    if (TR) {
+        for (int i = tid; i < NKEY * CH; i += 256) {               // rows >= T re-read row T-1: finite, and masked (p = 0) downstream
+            const int key = i / CH, c = (i % CH) ^ (key & 7);
+            const _Float16* src = base + (long)min(key, T - 1) * ld + c * 8;
+            __builtin_amdgcn_global_load_lds(ADVH_GLOBAL_PTR(src + H), ADVH_LDS_PTR((char*)Ks + (size_t)(i - lane) * 16), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(ADVH_GLOBAL_PTR(src + 2 * H), ADVH_LDS_PTR((char*)Vs + (size_t)(i - lane) * 16), 16, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else
     for (int i = tid; i < NKEY * CH; i += 256) {
         int key = i / CH, c = i % CH;
         f16x8 kv = {0, 0, 0, 0, 0, 0, 0, 0}, vv = kv;
@@ -249,10 +282,16 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const _Float16* __re
         for (int ss = 0; ss < NS; ++ss) {
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
-                const _Float16* kr = Kt + (dt * 16 + fr) * VP + (((dt * 16 + fr) >> 3) & 7) * 8 + ss * 32 + g * 4;
-                f16x4 lo = *(const f16x4*)kr;
-                f16x4 hi = (2 * ss + 1 < NT) ? *(const f16x4*)(kr + 16) : f16x4{0, 0, 0, 0};
-                f16x8 kf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                f16x8 kf;
+                if (TR) {                                           // K^T from the row-major tile; a missing odd tile re-reads the even one (dS = 0)
+                    const int ra = 32 * ss + 4 * g + tq;
+                    kf = tr_frag64(smem3, ra, (2 * ss + 1 < NT) ? ra + 16 : ra, dt * 16, tp);
+                } else {
+                    const _Float16* kr = Kt + (dt * 16 + fr) * VP + (((dt * 16 + fr) >> 3) & 7) * 8 + ss * 32 + g * 4;
+                    f16x4 lo = *(const f16x4*)kr;
+                    f16x4 hi = (2 * ss + 1 < NT) ? *(const f16x4*)(kr + 16) : f16x4{0, 0, 0, 0};
+                    kf = f16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                }
                 o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, dsf[ss], o[dt], 0, 0, 0);     // dQ^T [d][q]
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -269,6 +308,14 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const _Float16* __re
     __syncthreads();
 
     // ------------------------------------------------------------------ pass B: key tiles
+    if (TR) {
+        for (int i = tid; i < NKEY * CH; i += 256) {               // Q | dO row-major over the K | V space
+            const int row = i / CH, c = (i % CH) ^ (row & 7), rr = min(row, T - 1);
+            __builtin_amdgcn_global_load_lds(ADVH_GLOBAL_PTR(base + (long)rr * ld + c * 8), ADVH_LDS_PTR((char*)Ks + (size_t)(i - lane) * 16), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(ADVH_GLOBAL_PTR(dob + (long)rr * H + c * 8), ADVH_LDS_PTR((char*)Vs + (size_t)(i - lane) * 16), 16, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else
     for (int i = tid; i < NKEY * CH; i += 256) {
         int row = i / CH, c = i % CH;
         f16x8 qv = {0, 0, 0, 0, 0, 0, 0, 0}, ov = qv;
@@ -324,13 +371,20 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const _Float16* __re
             }
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
-                const _Float16* orow = dOt + (dt * 16 + fr) * VP + (((dt * 16 + fr) >> 3) & 7) * 8 + ss * 32 + g * 4;
-                const _Float16* qrow_ = Qt + (dt * 16 + fr) * VP + (((dt * 16 + fr) >> 3) & 7) * 8 + ss * 32 + g * 4;
-                f16x4 olo = *(const f16x4*)orow, qlo = *(const f16x4*)qrow_;
-                f16x4 ohi = (2 * ss + 1 < NT) ? *(const f16x4*)(orow + 16) : f16x4{0, 0, 0, 0};
-                f16x4 qhi = (2 * ss + 1 < NT) ? *(const f16x4*)(qrow_ + 16) : f16x4{0, 0, 0, 0};
-                f16x8 oa = {olo[0], olo[1], olo[2], olo[3], ohi[0], ohi[1], ohi[2], ohi[3]};
-                f16x8 qa = {qlo[0], qlo[1], qlo[2], qlo[3], qhi[0], qhi[1], qhi[2], qhi[3]};
+                f16x8 oa, qa;
+                if (TR) {                                           // dO^T and Q^T from the row-major tiles (Q over K's space, dO over V's)
+                    const int ra = 32 * ss + 4 * g + tq, rb = (2 * ss + 1 < NT) ? ra + 16 : ra;
+                    qa = tr_frag64(smem3, ra, rb, dt * 16, tp);
+                    oa = tr_frag64(smem3 + (size_t)ROWB * 2, ra, rb, dt * 16, tp);
+                } else {
+                    const _Float16* orow = dOt + (dt * 16 + fr) * VP + (((dt * 16 + fr) >> 3) & 7) * 8 + ss * 32 + g * 4;
+                    const _Float16* qrow_ = Qt + (dt * 16 + fr) * VP + (((dt * 16 + fr) >> 3) & 7) * 8 + ss * 32 + g * 4;
+                    f16x4 olo = *(const f16x4*)orow, qlo = *(const f16x4*)qrow_;
+                    f16x4 ohi = (2 * ss + 1 < NT) ? *(const f16x4*)(orow + 16) : f16x4{0, 0, 0, 0};
+                    f16x4 qhi = (2 * ss + 1 < NT) ? *(const f16x4*)(qrow_ + 16) : f16x4{0, 0, 0, 0};
+                    oa = f16x8{olo[0], olo[1], olo[2], olo[3], ohi[0], ohi[1], ohi[2], ohi[3]};
+                    qa = f16x8{qlo[0], qlo[1], qlo[2], qlo[3], qhi[0], qhi[1], qhi[2], qhi[3]};
+                }
                 dvt[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(oa, pf, dvt[dt], 0, 0, 0);      // dV^T [d][key]
                 dkt[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qa, dsf, dkt[dt], 0, 0, 0);     // dK^T [d][key]
             }
@@ -458,19 +512,19 @@ extern "C" int advh_layernorm_bwd(const void* x, int x_is_f32, const void* dy, i
     return ADVH_LAUNCH_CHECK();
 }
 
-template <int NT, int D>
+template <int NT, int D, bool TR>
 static int launch_att_bwd(const void* qkv, const void* dctx, void* dqkv, int B, int T, int H, int heads, int dm, float scale, hipStream_t s) {
-    constexpr int NKEY = NT * 16, VP = NKEY + 64, ROWB = NKEY * D, TRB = D * VP;
-    constexpr int PA = D <= 64 ? 2 * ROWB + TRB : ROWB + TRB;
+    constexpr int NKEY = NT * 16, VP = NKEY + 64, ROWB = NKEY * D, TRB = TR ? 0 : D * VP;
+    constexpr int PA = TR ? 2 * ROWB : (D <= 64 ? 2 * ROWB + TRB : ROWB + TRB);
     const size_t lds = (size_t)(PA > 2 * TRB ? PA : 2 * TRB) * 2 + 3 * NKEY * 4;
     if (lds > 160 * 1024) return ADVH_EUNSUPPORTED;
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)attention_bwd_kernel<NT, D>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)attention_bwd_kernel<NT, D, TR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return ADVH_ELAUNCH;
         attr_done = true;
     }
-    hipLaunchKernelGGL((attention_bwd_kernel<NT, D>), dim3(heads, B), dim3(256), lds, s, (const _Float16*)qkv, (const _Float16*)dctx,
+    hipLaunchKernelGGL((attention_bwd_kernel<NT, D, TR>), dim3(heads, B), dim3(256), lds, s, (const _Float16*)qkv, (const _Float16*)dctx,
                        (_Float16*)dqkv, T, H, dm, scale);
     return ADVH_LAUNCH_CHECK();
 }
@@ -484,11 +538,14 @@ extern "C" int advh_attention_bwd_f16(const void* qkv, const void* dctx, void* d
     const float scale = 1.f / sqrtf((float)dm);
     hipStream_t s = (hipStream_t)stream;
     const int nt = (T + 15) / 16;
-#define ATB(NT_, D_) return launch_att_bwd<NT_, D_>(qkv, dctx, dqkv, B, T, H, heads, dm, scale, s)
-    if (D == 64) { if (nt <= 4) ATB(4, 64); else if (nt <= 8) ATB(8, 64); else if (nt <= 13) ATB(13, 64); else ATB(16, 64); }
+#define ATB(NT_, D_) return launch_att_bwd<NT_, D_, false>(qkv, dctx, dqkv, B, T, H, heads, dm, scale, s)
+#define ATBT(NT_) return launch_att_bwd<NT_, 64, true>(qkv, dctx, dqkv, B, T, H, heads, dm, scale, s)
+    if (dm == 64) { if (nt <= 4) ATBT(4); else if (nt <= 8) ATBT(8); else if (nt <= 13) ATBT(13); else ATBT(16); }
+    else if (D == 64) { if (nt <= 4) ATB(4, 64); else if (nt <= 8) ATB(8, 64); else if (nt <= 13) ATB(13, 64); else ATB(16, 64); }
     else if (D == 32) { if (nt <= 4) ATB(4, 32); else if (nt <= 8) ATB(8, 32); else if (nt <= 13) ATB(13, 32); else ATB(16, 32); }
     else { if (nt <= 4) ATB(4, 128); else if (nt <= 13) ATB(13, 128); else ATB(16, 128); }
 #undef ATB
+#undef ATBT
 }
 
 extern "C" int advh_pool_logreg_bwd(const float* coef, const float* dlogit, float* dh, void* dh16, int B, int T, int H,
