@@ -386,6 +386,25 @@ typedef struct advh_wgrad2d_desc {
 int advh_conv_wgrad2d_parts(int C, int B, int H, int W);
 int advh_conv_wgrad2d_f16(const advh_wgrad2d_desc* d, int C, float* dw, advh_stream_t stream);
 
+/* One fused HiFi-GAN ResBlock1 step for the 32- / 64-channel stages (speechbrain HifiganGenerator via hifigan.py:106-110,
+ * 180): out = x + conv2(lrelu(conv1(lrelu(x)))) on a zero-haloed channels-last fp16 map [M][C] (rows m with
+ * w0 <= m % Wg < w1 are real samples; the others are written as zeros); conv1: k taps, dilation dil, conv2: k taps,
+ * dilation 1, both "same"; W1 / W2 [k][C_out][C_in] fp16, b1 / b2 [C] fp32.  The intermediate map stays in LDS.  X and
+ * out_h must be different maps.  ADVH_EUNSUPPORTED when both weight tensors + line buffers exceed 160 KiB
+ * (advh_resblock_pair_lds_bytes): the caller then launches the two convolutions separately.                         */
+typedef struct advh_resblock_desc {
+    const void* X;
+    const void* W1;
+    const float* b1;
+    const void* W2;
+    const float* b2;
+    void* out_h;
+    int M, Wg, w0, w1, k, dil;
+    float slope;
+} advh_resblock_desc;
+int advh_resblock_pair_lds_bytes(int C, int k, int dil);
+int advh_resblock_pair_f16(const advh_resblock_desc* d, int C, advh_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

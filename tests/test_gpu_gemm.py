@@ -213,3 +213,28 @@ def test_conv2d_line_tile(gpu_device, Cn, B, H, W, PH, PW):
     close(dst.t, d2.t.cpu())
     assert not G.taps2d_supported([src], G.FMap(B, H, W, Cn, PH + 1, PW), w)
     assert not G.taps2d_supported([src], dst, rnd(g, Cn, Cn, 3, 3), stride=(2, 2))
+
+
+@pytest.mark.parametrize("Cn,k,d,B,T", [(32, 3, 1, 2, 500), (32, 7, 3, 1, 1000), (32, 11, 5, 3, 777), (64, 3, 5, 2, 300), (64, 3, 1, 1, 2049), (64, 7, 5, 2, 600)])
+def test_fused_resblock_step(gpu_device, Cn, k, d, B, T):
+    """csrc/resblock_pair.hip (x + conv2(lrelu(conv1(lrelu(x)))), intermediate map in LDS) against torch on the same fp16
+    operands with the intermediate rounded to fp16 as the kernel stores it; halo rows come out zero."""
+    _lib.init()
+    g = torch.Generator().manual_seed(Cn + k + d)
+    src, dst = G.Map1D(B, T, Cn, 32).alloc(gpu_device), G.Map1D(B, T, Cn, 32).alloc(gpu_device)
+    x = rnd(g, B, Cn, T)
+    src.interior()[:] = x.transpose(1, 2).half().to(gpu_device)
+    w1, w2 = rnd(g, Cn, Cn, k) / (Cn * k) ** 0.5, rnd(g, Cn, Cn, k) / (Cn * k) ** 0.5
+    b1, b2 = rnd(g, Cn) * 0.1, rnd(g, Cn) * 0.1
+    assert G.resblock_pair_supported(src, dst, w1, w2, d)
+    p = G.ResblockPairPlan(src, dst, w1, b1, w2, b2, dilation=d, slope=0.1, device=gpu_device)
+    dst.t.fill_(float("nan"))
+    p.run(src.t, out_h=dst.t)
+    torch.cuda.synchronize()
+    xh = x.half().float()
+    a = F.leaky_relu(xh, 0.1).half().float()
+    t = F.leaky_relu(F.conv1d(a, w1.half().float(), b1, padding=(k - 1) * d // 2, dilation=d), 0.1).half().float()
+    ref = xh + F.conv1d(t, w2.half().float(), b2, padding=(k - 1) // 2)
+    close(dst.interior().transpose(1, 2), ref, tol=3e-3)
+    assert (dst.t[:, :32] == 0).all() and (dst.t[:, 32 + T:] == 0).all()
+    assert not G.resblock_pair_supported(src, dst, rnd(g, 64, 64, 11), rnd(g, 64, 64, 11), 1) or Cn != 64    # 2 x 90 KB of weights

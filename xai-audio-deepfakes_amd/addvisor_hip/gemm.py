@@ -626,6 +626,58 @@ class Taps2dPlan:
         _lib.check(_lib.lib().advh_conv_taps2d_f16(C.byref(d), self.Cn, stream), "advh_conv_taps2d_f16")
 
 
+class ResblockDesc(C.Structure):
+    """Mirror of ``advh_resblock_desc`` (include/addvisor_hip.h)."""
+    _fields_ = [("X", C.c_void_p), ("W1", C.c_void_p), ("b1", C.c_void_p), ("W2", C.c_void_p), ("b2", C.c_void_p),
+                ("out_h", C.c_void_p), ("M", C.c_int), ("Wg", C.c_int), ("w0", C.c_int), ("w1", C.c_int), ("k", C.c_int),
+                ("dil", C.c_int), ("slope", C.c_float)]
+
+
+def resblock_pair_lds_bytes(Cn: int, k: int, dil: int) -> int:
+    """Host copy of ``advh_resblock_pair_lds_bytes``: both weight tensors + one line buffer (which later holds the
+    intermediate tile) if that fits 80 KiB (two workgroups per CU), else two line buffers."""
+    rows = max(256 + (k - 1) * dil, 272)
+    buf = ((rows * (Cn // 8) + 63) // 64 * 64) * 16
+    one = 2 * k * Cn * Cn * 2 + buf
+    return one if (one <= 80 * 1024 or one + buf > TAPS_MAX_LDS) else one + buf
+
+
+def resblock_pair_supported(src: Map1D, dst: Map1D, w1: torch.Tensor, w2: torch.Tensor, dilation: int) -> bool:
+    Cn, k = w1.shape[0], w1.shape[2]
+    return (Cn in (32, 64) and tuple(w1.shape) == (Cn, Cn, k) and tuple(w2.shape) == (Cn, Cn, k) and k % 2 == 1 and src.C == Cn
+            and dst.C == Cn and (src.B, src.T, src.halo) == (dst.B, dst.T, dst.halo) and src.halo >= (k - 1) * dilation // 2
+            and resblock_pair_lds_bytes(Cn, k, dilation) <= TAPS_MAX_LDS)
+
+
+class ResblockPairPlan:
+    """One launch of ``advh_resblock_pair_f16``: ``dst = src + conv2(lrelu(conv1(lrelu(src))))`` (HiFi-GAN ResBlock1 step)."""
+
+    def __init__(self, src: Map1D, dst: Map1D, w1, b1, w2, b2, *, dilation: int, slope: float, device=None):
+        assert resblock_pair_supported(src, dst, w1, w2, dilation)
+        Cn, k = w1.shape[0], w1.shape[2]
+        self.Cn = Cn
+        pack = lambda w: w.permute(2, 0, 1).to(torch.float16).contiguous()
+        self.w1, self.w2 = pack(w1), pack(w2)
+        self.b1, self.b2 = b1.to(torch.float32).contiguous(), b2.to(torch.float32).contiguous()
+        if device is not None:
+            self.w1, self.w2, self.b1, self.b2 = (t.to(device) for t in (self.w1, self.w2, self.b1, self.b2))
+        d = ResblockDesc()
+        d.M, d.Wg, d.w0, d.w1, d.k, d.dil, d.slope = dst.B * dst.P, dst.P, dst.halo, dst.halo + dst.T, k, dilation, slope
+        self.desc = d
+        self.flops = 2 * 2.0 * dst.B * dst.T * Cn * Cn * k
+
+    def run(self, A0: torch.Tensor, A1=None, *, out_h: torch.Tensor, stream: Optional[int] = None, **_):
+        d = self.desc
+        for t in (A0, out_h):
+            assert t.dtype == torch.float16 and t.is_cuda and t.is_contiguous() and t.numel() == d.M * self.Cn
+        assert A0.data_ptr() != out_h.data_ptr()
+        d.X, d.out_h = A0.data_ptr(), out_h.data_ptr()
+        d.W1, d.W2, d.b1, d.b2 = self.w1.data_ptr(), self.w2.data_ptr(), self.b1.data_ptr(), self.b2.data_ptr()
+        if stream is None:
+            stream = torch.cuda.current_stream().cuda_stream
+        _lib.check(_lib.lib().advh_resblock_pair_f16(C.byref(d), self.Cn, stream), "advh_resblock_pair_f16")
+
+
 def taps_supported(src: Map1D, dst: Map1D, weight: torch.Tensor, dilation: int) -> bool:
     Cout, Cin, k = weight.shape
     return (Cout == Cin and Cin in (32, 64) and src.C == Cin and dst.C == Cout and src.halo == dst.halo and k <= 16

@@ -19,11 +19,12 @@ HALO = 32          # >= the largest "same" padding: (11 - 1) * 5 / 2 = 25
 
 
 class HipHifigan:
-    def __init__(self, cfg: HifiganConfig, sd: Dict[str, torch.Tensor], device, line_tile: bool = True):
+    def __init__(self, cfg: HifiganConfig, sd: Dict[str, torch.Tensor], device, line_tile: bool = True, fuse: bool = True):
         """``line_tile``: run the 32- / 64-channel ResBlock convolutions on the weights-in-LDS kernel
-        (``advh_conv_taps_f16``) instead of the implicit GEMM."""
+        (``advh_conv_taps_f16``) instead of the implicit GEMM; ``fuse``: whole ResBlock steps in one kernel where both
+        weight tensors fit in LDS (``advh_resblock_pair_f16``)."""
         _lib.init()
-        self.cfg, self.dev, self.line_tile = cfg, device, line_tile
+        self.cfg, self.dev, self.line_tile, self.fuse = cfg, device, line_tile, fuse
         self.sd = {k: v.detach().float() for k, v in sd.items()}
         ch = cfg.upsample_initial_channel
         for _ in cfg.upsample_rates:
@@ -76,12 +77,20 @@ class HipHifigan:
                 cx, clx = x, lx
                 for d in range(nd):
                     last = d == nd - 1
+                    ox = outs[j] if last else (pa if d % 2 == 0 else pb)
+                    w1, w2 = sd[p + f"convs1.{d}.weight"], sd[p + f"convs2.{d}.weight"]
+                    if in_lds and self.fuse and G.resblock_pair_supported(cx, ox, w1, w2, cfg.resblock_dilations[d]):
+                        # both convolutions of the step in one kernel, the intermediate map stays in LDS
+                        steps.append(("gemm", G.ResblockPairPlan(cx, ox, w1, sd[p + f"convs1.{d}.bias"], w2, sd[p + f"convs2.{d}.bias"],
+                                                                dilation=cfg.resblock_dilations[d], slope=cfg.leaky_slope, device=dev),
+                                      cx, None, ox, None))
+                        cx, clx = ox, None
+                        continue
                     c1_src = cx if in_lds else clx
                     steps.append(("gemm", conv(c1_src, tmp, sd[p + f"convs1.{d}.weight"], sd[p + f"convs1.{d}.bias"],
                                                dilation=cfg.resblock_dilations[d], act="leaky", slope=cfg.leaky_slope,
                                                **(dict(pre_slope=cfg.leaky_slope) if in_lds else {})),
                                   c1_src, None, tmp, None))
-                    ox = outs[j] if last else (pa if d % 2 == 0 else pb)
                     ol = None if (last or in_lds) else (la if d % 2 == 0 else lb)
                     steps.append(("gemm", conv(tmp, ox, sd[p + f"convs2.{d}.weight"], sd[p + f"convs2.{d}.bias"],
                                                slope2=cfg.leaky_slope), tmp, cx, ox, ol))
