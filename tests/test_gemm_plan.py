@@ -164,3 +164,26 @@ def test_line_tile_swizzles_are_conflict_free():
         for g in groups:
             slots = {((base + (l & 15)) * 64 + (((l >> 4) ^ (((base + (l & 15)) >> 1) & 2)) * 16)) % 256 // 16 for l in g}
             assert len(slots) == 16
+
+
+def test_line_tile_host_rules_match_the_library():
+    """The host copies of the LDS-footprint rules (which layers go to the line-tile / fused kernels) agree with the C
+    entry points, and the eligibility predicates reject what the kernels do not take."""
+    from addvisor_hip import _lib
+    lib = _lib.lib()
+    for Cn in (32, 64):
+        for k in (3, 7, 11):
+            for d in (1, 3, 5):
+                assert G.taps_tile(Cn, k, (k - 1) * d) == lib.advh_conv_taps_tile(Cn, k, (k - 1) * d)
+                assert G.taps_lds_bytes(Cn, k, (k - 1) * d) == lib.advh_conv_taps_lds_bytes(Cn, k, (k - 1) * d)
+                c_bytes = lib.advh_resblock_pair_lds_bytes(Cn, k, d)
+                assert G.resblock_pair_lds_bytes(Cn, k, d) == c_bytes or c_bytes > 160 * 1024
+    s32, d32 = G.Map1D(1, 100, 32, 32), G.Map1D(1, 100, 32, 32)
+    assert G.resblock_pair_supported(s32, d32, rnd(32, 32, 11), rnd(32, 32, 11), 5)
+    assert not G.resblock_pair_supported(G.Map1D(1, 100, 64, 32), G.Map1D(1, 100, 64, 32), rnd(64, 64, 11), rnd(64, 64, 11), 1)
+    assert not G.resblock_pair_supported(s32, G.Map1D(1, 100, 32, 16), rnd(32, 32, 3), rnd(32, 32, 3), 1)
+    a, b = G.FMap(2, 16, 16, 64, 1, 1), G.FMap(2, 16, 16, 64, 1, 1)
+    assert G.taps2d_supported([a], b, rnd(64, 64, 3, 3))
+    assert not G.taps2d_supported([a], b, rnd(64, 64, 3, 3), dilation=(2, 2))
+    assert not G.taps2d_supported([a, a], b, rnd(64, 128, 3, 3))
+    assert not G.taps2d_supported([G.FMap(2, 16, 16, 128, 1, 1)], G.FMap(2, 16, 16, 128, 1, 1), rnd(128, 128, 3, 3))
