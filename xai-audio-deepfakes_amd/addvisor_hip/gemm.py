@@ -71,7 +71,7 @@ class _Profile:
     def summary(self, tile=None):
         """(ms, flops, launches) of ``tile``; default: the tile with the largest total time."""
         per = {}
-        for a, b, f, t in self.events:
+        for a, b, f, t, _ in self.events:
             r = per.setdefault(t, [0.0, 0.0, 0])
             r[0] += a.elapsed_time(b); r[1] += f; r[2] += 1
         if not per:
@@ -80,6 +80,14 @@ class _Profile:
             tile = max(per, key=lambda t: per[t][0])
         self.tile = tile
         return tuple(per.get(tile, (0.0, 0.0, 0)))
+
+    def by_shape(self):
+        """{(M, N, K, nz, tile name): [ms, flops, launches]} of the recorded launches (tools/bench_shapes.py)."""
+        per = {}
+        for a, b, f, t, shape in self.events:
+            r = per.setdefault(shape + (TILE_NAMES.get(t, str(t)),), [0.0, 0.0, 0])
+            r[0] += a.elapsed_time(b); r[1] += f; r[2] += 1
+        return per
 
 
 PROFILE = _Profile()
@@ -271,7 +279,7 @@ class GemmPlan:
         _lib.check(_lib.lib().advh_gemm_f16(C.byref(d), self.tile, stream), "advh_gemm_f16")
         if prof:
             e1.record()
-            PROFILE.events.append((e0, e1, self.flops, self.tile))
+            PROFILE.events.append((e0, e1, self.flops, self.tile, (self.desc.M, self.desc.N, self.K, self.desc.nz)))
 
 
 def _tune(self, d, stream):
