@@ -168,6 +168,15 @@ typedef struct advh_gemm_desc {
        q = n / n_div, the offset is (q / n_sub)*o_sNhh + (q % n_sub)*o_sNhi instead of q*o_sNhi; n_sub <= 1 = off. */
     int32_t n_sub;
     int64_t o_sNhh;
+    /* two-level grid-z batch (256-thread kernels only; the other tiles return ADVH_EUNSUPPORTED): with nz_lo > 1 the
+       batch index z in [0, nz) splits into zh = z / nz_lo, zw = z % nz_lo and the operands advance by
+       a_sZ*zh + a_sZ2*zw (chunks) and o_sZ*zh + o_sZ2*zw (elements); W and bias still advance by w_sZ*z, bias_sZ*z.
+       The four output-parity classes of a fused ConvTranspose2d(2,2)+Conv2d launch are such a batch.
+       z_inner = 1: the nz batches of one tile are dispatched next to each other (z fastest in the workgroup order)
+       instead of batch after batch, so batches that read the same operand rows meet in L2.                  */
+    int32_t nz_lo, z_inner;
+    int64_t a_sZ2[2];
+    int64_t o_sZ2;
 } advh_gemm_desc;
 
 int advh_gemm_f16(const advh_gemm_desc* desc, int tile, advh_stream_t stream);
@@ -215,7 +224,8 @@ int advh_pool_logreg(const float* h, const float* coef, float intercept, float* 
  * H x W crop is taken by indexing.  NHWC maps are fp16 with a zero halo (PH, PW).
  * advh_unet_stem : e1.block.0 Conv2d(1,32,(5,3),stride (2,1),pad (2,1)) + folded BN + LeakyReLU;
  *                  wgt [32][15], out [B][H/2+2PH][W+2PW][32] (interior written).
- * advh_unet_pack_x: channels [c0,c0+8) of the C-channel d1 concat map <- (mag, 0 x7)  (addvisor.py:79).
+ * advh_unet_pack_x: channels [c0,c0+8) of the C-channel d1 concat map <- (mag, 1, 0 x6)  (addvisor.py:79); the 1 is
+ *                  the in-image indicator the fused ConvTranspose2d+Conv2d launch multiplies up1's bias with.
  * advh_unet_head : mask_head Conv2d(32,1,1) + Sigmoid -> mask (and pre-sigmoid logits) [B][H][W] fp32. */
 int advh_unet_stem(const float* mag, int Fq, int Tq, int B, int H, int W, const float* wgt, const float* bias,
                    void* out, int PH, int PW, float slope, advh_stream_t stream);

@@ -89,6 +89,51 @@ def test_convT2d_plan():
         assert torch.isnan(out).all()                          # nothing else is touched
 
 
+def upconv_case(stride, Cb, Cu, Cs, N, Hc, Wc, where, B=2, cpad=0):
+    """Fused ConvTranspose2d -> cat -> Conv2d 3x3 -> LeakyReLU (addvisor.py:45-46,69-71) vs the three torch ops."""
+    sh, sw = stride
+    xb, xs = rnd(B, Cb, Hc, Wc), rnd(B, Cs, Hc * sh, Wc * sw)
+    wt, bt = rnd(Cb, Cu, sh, sw) * 0.3, rnd(Cu)
+    wc, bc = rnd(N, Cu + Cs, 3, 3) * 0.2, rnd(N)
+    up = F.conv_transpose2d(xb.half().float(), wt, bt, stride=stride)
+    ref = F.leaky_relu(F.conv2d(torch.cat([up, xs.half().float()], 1), wc, bc, padding=1), 0.2)
+    cC = G.round_up(Cb, 8) + (8 if where == "coarse" else 0) + cpad     # cpad: unused channels up to a 128-byte pixel pitch
+    sC = G.round_up(Cs + (1 if where == "skip" else 0), 8)
+    coarse = fill_part(G.FMap(B, Hc, Wc, cC, 1, 2), xb)
+    skip = fill_part(G.FMap(B, Hc * sh, Wc * sw, sC, 2, 1), xs)
+    ich = G.round_up(Cb, 8) if where == "coarse" else Cs
+    G.add_indicator(coarse if where == "coarse" else skip, ich)
+    dst = G.FMap(B, Hc * sh, Wc * sw, N, 1, 1)
+    grp = G.plan_upconv2d(coarse, skip, dst, wt, bt, wc, bc, stride=stride, coarse_C=Cb, skip_C=Cs, indicator=(where, ich))
+    assert len(grp.plans) == 1 and grp.plans[0].desc.nz == sh * sw and grp.plans[0].desc.z_inner == 1
+    out = torch.zeros(B * dst.Hp * dst.Wp * N)
+    for p in grp.plans:
+        out = G.replay_on_cpu(p, coarse.t, skip.t, out.numel(), out_init=out)
+    out = out.view(B, dst.Hp, dst.Wp, N)
+    inner = out[:, 1:1 + dst.H, 1:1 + dst.W].permute(0, 3, 1, 2)
+    # composed weights are rounded to fp16 once (instead of wt, wc separately): compare at fp16 weight resolution
+    assert torch.allclose(inner, ref, atol=6e-3), (inner - ref).abs().max()
+    halo = out.clone()
+    halo[:, 1:1 + dst.H, 1:1 + dst.W] = 0
+    assert (halo == 0).all()                                   # only the interior is written
+    return (inner - ref).abs().max().item()
+
+
+def fill_part(f: G.FMap, x_nchw: torch.Tensor):
+    f.t = torch.zeros((f.B, f.Hp, f.Wp, f.C), dtype=torch.float16)
+    f.interior()[..., :x_nchw.shape[1]] = x_nchw.permute(0, 2, 3, 1).to(torch.float16)
+    return f
+
+
+def test_upconv2d_plans():
+    errs = [upconv_case((2, 2), 16, 8, 8, 8, 3, 4, "coarse"),      # up4 + d4 / up3 + d3 style
+            upconv_case((2, 1), 16, 8, 8, 16, 3, 5, "coarse"),     # up2 + d2: stride (2, 1), 3 column taps
+            upconv_case((2, 1), 8, 8, 1, 8, 4, 3, "skip"),         # up1 + d1: 1-channel skip (the spectrogram) carries the indicator
+            upconv_case((2, 2), 8, 16, 16, 8, 1, 1, "coarse"),     # single coarse pixel: every tap hits a border
+            upconv_case((2, 2), 16, 8, 8, 8, 2, 3, "coarse", cpad=40)]   # 24 used channels in a 64-channel (128-byte) pitch
+    assert max(errs) < 6e-3                                    # measured 1.2e-3 ... 1.9e-3
+
+
 def test_conv1d_same_and_convT1d_plans():
     """HiFi-GAN layers: dilated "same" Conv1d and phase-decomposed ConvTranspose1d (k = 2*stride)."""
     B, T, C = 2, 13, 16

@@ -49,6 +49,27 @@ def test_unet_small(gpu_device, shape, golden):
         assert (mask.cpu() - torch.from_numpy(golden("unet.npz")["out_a"])[:, 0]).abs().max().item() <= TOL_MASK
 
 
+@pytest.mark.parametrize("shape", [(2, 32, 8), (2, 64, 20)])
+def test_unet_fused_up_matches_unfused(gpu_device, shape):
+    """``fuse_up`` (ConvTranspose2d folded into the following Conv2d, gemm.plan_upconv2d) against the layer-by-layer
+    path and the oracle, with the transposed convolutions' biases scaled up so the border handling of the bias
+    (in-image indicator channel) carries weight.  Stated tolerance between the two HIP paths: 4e-3 on the mask."""
+    sd = {k: v.clone() for k, v in syn.unet_weights().items()}
+    for n in ("up1", "up2", "up3", "up4"):
+        sd[n + ".bias"] = sd[n + ".bias"] * 8.0
+    B, H, W = shape
+    r = np.random.Generator(np.random.PCG64(7 + H))
+    x = torch.from_numpy(r.uniform(0, 3, size=(B, 1, H, W)).astype(np.float32))
+    ref = unet_ref.unet_forward(x, sd)[:, 0]
+    fused = HipUNet(sd, gpu_device, fuse_up=True).forward(x[:, 0].to(gpu_device), H=H, W=W)
+    plain = HipUNet(sd, gpu_device, fuse_up=False).forward(x[:, 0].to(gpu_device), H=H, W=W)
+    check(fused, ref)
+    check(plain, ref)
+    d = (fused - plain).abs().max().item()
+    print(f"fused vs layer-by-layer: max {d:.3e}")
+    assert d <= 4e-3
+
+
 def test_unet_full_size(gpu_device, golden):
     """512 x 196 crop of a real 4 s STFT magnitude (the BASELINE shape), one clip + batch neighbours."""
     sd = syn.unet_weights()

@@ -9,7 +9,7 @@ from addvisor_hip.unet import HipUNet
 torch.set_grad_enabled(False)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 dev = torch.device("cuda:0")
-net = HipUNet(syn.unet_weights(), dev)
+net = HipUNet(syn.unet_weights(), dev, fuse_up=os.environ.get("UNET_FUSE_UP", "1") != "0")
 mag = torch.rand(B, 513, 199, device=dev)
 net.forward(mag); torch.cuda.synchronize()
 ws = net._workspace(B, 512, 196)
@@ -24,6 +24,6 @@ for plan, srcs, dst in ws["steps"]:
     e1.record(); e1.synchronize()
     ms = e0.elapsed_time(e1) / 5
     tot += ms
-    kind = "taps2d" if isinstance(plan, G.Taps2dPlan) else G.TILE_NAMES[plan.tile]
+    kind = "taps2d" if isinstance(plan, G.Taps2dPlan) else G.TILE_NAMES[plan.tile] + ("*" if isinstance(plan, G.PlanGroup) else "")
     print(f"{'+'.join(srcs):8s} -> {dst:4s} {kind:9s} {ms*1e3:8.1f} us  {plan.flops/ms/1e9:7.1f} TFLOP/s  ({plan.flops/1e9:6.1f} GF)")
 print(f"total GEMM-shaped layers {tot:.3f} ms")

@@ -55,6 +55,7 @@ class GemmDesc(C.Structure):
         ("resid_f32", C.c_int32), ("ktab_identity", C.c_int32),
         ("out_h2", C.c_void_p), ("slope2", C.c_float), ("ph_r", C.c_int32), ("ph_pad", C.c_int32), ("ph_T", C.c_int32),
         ("out_pre", C.c_void_p), ("dact_src", C.c_void_p), ("wide", C.c_int32), ("w_ld", C.c_int64), ("sc", C.c_int32), ("n_sub", C.c_int32), ("o_sNhh", C.c_int64),
+        ("nz_lo", C.c_int32), ("z_inner", C.c_int32), ("a_sZ2", C.c_int64 * 2), ("o_sZ2", C.c_int64),
     ]
 
 
@@ -143,6 +144,7 @@ class Source:
     sW: int
     c0: int
     sZ: int = 0
+    sZ2: int = 0
 
 
 class GemmPlan:
@@ -154,7 +156,7 @@ class GemmPlan:
                  o_sZ: int = 0, nz: int = 1, bias: Optional[torch.Tensor] = None, act: str = "none",
                  slope: float = 0.0, device=None, w_sZ: Optional[int] = None, bias_sZ: int = 0,
                  slope2: float = 0.0, phase: Tuple[int, int, int] = (0, 0, 0), cache: Optional[tuple] = None,
-                 n_sub: int = 0, o_sNhh: int = 0):
+                 n_sub: int = 0, o_sNhh: int = 0, nz_lo: int = 0, z_inner: bool = False, o_sZ2: int = 0):
         """``w2``: fp32 ``[nz, N, K]`` (K = 8 * len(ktab) before padding) or a zero-argument callable returning it
         (only called when the packed weight is not in ``cache``); ``ktab``: int64 chunk offsets with bit 31 as
         source selector; ``out`` = (o_sB, o_sH, o_sW, o_c0) in elements.  ``cache = (dict, key)`` shares the
@@ -164,7 +166,7 @@ class GemmPlan:
         Kp = round_up(K, BK)
         n_div_v = n_div if n_div is not None else round_up(N, 4)
         # 16-byte epilogue stores need 8 consecutive channels per lane (permuted weight rows) and 8-aligned addressing
-        wide = WIDE_EPILOGUE and N % 8 == 0 and n_div_v % 8 == 0 and all(int(x) % 8 == 0 for x in (*out, o_sNhi, o_sZ, o_sNhh))
+        wide = WIDE_EPILOGUE and N % 8 == 0 and n_div_v % 8 == 0 and all(int(x) % 8 == 0 for x in (*out, o_sNhi, o_sZ, o_sNhh, o_sZ2))
         tile, BN = pick_tile(N, M)
         if W8_RULE and N % 256 == 0 and M >= W8_RULE and bool((np.asarray(ktab) == np.arange(len(ktab))).all()):
             tile, BN = TILE_128x256_W8, 256                    # experiment switch: plain wide GEMMs on the 512-thread tile
@@ -206,11 +208,14 @@ class GemmPlan:
         d.halo_zero = int(halo_zero)
         for s, src in enumerate(sources):
             d.a_sB[s], d.a_sH[s], d.a_sW[s], d.a_c0[s], d.a_sZ[s] = src.sB, src.sH, src.sW, src.c0, src.sZ
+            d.a_sZ2[s] = src.sZ2
         d.w_sZ = w_rows * Kp if w_sZ is None else w_sZ
         d.bias_sZ = bias_sZ
         d.o_sB, d.o_sH, d.o_sW, d.o_c0 = out
         d.o_sNhi, d.o_sZ = o_sNhi, o_sZ
         d.n_sub, d.o_sNhh = n_sub, o_sNhh
+        d.nz_lo, d.z_inner, d.o_sZ2 = nz_lo, int(z_inner), o_sZ2
+        assert nz_lo <= 1 or nz % nz_lo == 0
         d.n_div = n_div_v
         d.wide = int(wide)
         d.nz = nz
@@ -284,6 +289,8 @@ class GemmPlan:
 
 def _tune(self, d, stream):
     cands = [TILE_128x128, TILE_128x256_W8, TILE_256x128_W8, TILE_256x256] if self.desc.N > 64 else [self.tile]
+    if self.desc.nz_lo > 1 or self.desc.z_inner:
+        cands = [c for c in cands if c != TILE_256x256]       # the two-level batch lives in gemm_f16_kernel only
     best, best_ms = self.tile, None
     if len(cands) > 1:
         for t in cands:
@@ -419,6 +426,97 @@ def plan_convT2d(src: FMap, dst: FMap, weight: torch.Tensor, bias: torch.Tensor,
                     bias=b2, bias_sZ=0, act="none", device=device)
 
 
+class PlanGroup:
+    """Several launches that together produce one map (``plan_upconv2d``); same ``run`` signature as one plan."""
+
+    def __init__(self, plans: Sequence[GemmPlan], flops: float):
+        self.plans, self.flops = list(plans), flops
+        self.tile = self.plans[0].tile
+
+    def run(self, A0: torch.Tensor, A1: Optional[torch.Tensor] = None, *, out_h: torch.Tensor, stream: Optional[int] = None):
+        for p in self.plans:
+            p.run(A0, A1, out_h=out_h, stream=stream)
+
+
+def add_indicator(f: FMap, channel: int) -> FMap:
+    """Set channel ``channel`` of an allocated map to 1 inside the image (halo stays 0): the in-image indicator the
+    fused up-convolution multiplies the transposed convolution's bias with."""
+    f.t[:, f.PH:f.PH + f.H, f.PW:f.PW + f.W, channel] = 1.0
+    return f
+
+
+def plan_upconv2d(coarse: FMap, skip: FMap, dst: FMap, wt: torch.Tensor, bt: torch.Tensor, wc: torch.Tensor,
+                  bc: torch.Tensor, *, stride, coarse_C: int, skip_C: int, indicator: Tuple[str, int],
+                  slope: float = 0.2, device=None) -> PlanGroup:
+    """``conv3x3(cat([ConvTranspose2d(coarse), skip])) + bias -> LeakyReLU`` (addvisor.py:45-46,69-71 and the three
+    blocks after it) WITHOUT materialising the up-sampled map.  A transposed convolution with kernel == stride is
+    pointwise in its input pixel, so for output pixels of one parity class (oh % sh, ow % sw) the 3x3 window over the
+    up-sampled map is a small convolution over the COARSE map with composed weights
+    ``sum_cu wc[n, cu, kh, kw] * wt[cb, cu, (ph+kh-1) % sh, (pw+kw-1) % sw]`` at coarse tap
+    ``((ph+kh-1) // sh, (pw+kw-1) // sw)``: 2 coarse taps per strided axis, 3 per unstrided one.  The transposed
+    convolution's bias reaches an output only through window positions inside the image, so it is multiplied with an
+    in-image indicator channel (``indicator = ("coarse" | "skip", channel)``, set once by ``add_indicator``; zero in the halo)
+    through the composed weight ``sum_cu wc[n, cu, kh, kw] * bt[cu]``.  One launch per column parity, row parities in grid z.
+
+    ``wt [Cb, Cu, sh, sw]``, ``bt [Cu]``: the ConvTranspose2d; ``wc [N, Cu + Cs, 3, 3]``, ``bc [N]``: the (BN-folded)
+    convolution; ``coarse_C`` / ``skip_C``: real channel counts (the maps may be wider: indicator chunk, zero padding).
+    Only ``dst``'s interior is written; its halo must already be zero."""
+    sh, sw = stride
+    Cb, Cu = wt.shape[:2]
+    N = wc.shape[0]
+    Cs = wc.shape[1] - Cu
+    assert (wt.shape[2], wt.shape[3]) == (sh, sw) and sh == 2 and sw in (1, 2) and wc.shape[2:] == (3, 3)
+    assert coarse_C == Cb and skip_C == Cs and coarse.C >= Cb and skip.C >= Cs and coarse.C % 8 == 0 and skip.C % 8 == 0
+    assert (dst.H, dst.W) == (coarse.H * sh, coarse.W * sw) == (skip.H, skip.W) and dst.B == coarse.B == skip.B
+    assert coarse.PH >= 1 and coarse.PW >= 1 and skip.PH >= 1 and skip.PW >= 1 and dst.C % 8 == 0
+    where, ich = indicator
+    assert where in ("coarse", "skip") and ich >= (Cb if where == "coarse" else Cs)
+    wt64, wc64, bt64 = wt.double(), wc.double(), bt.double()
+    nth, ntw = 2, (2 if sw == 2 else 3)
+    cc0, cc1, Ct = coarse.C // 8, skip.C // 8, dst.C                       # pixel pitch of the maps in chunks
+    cu0 = (max(Cb, ich + 1 if where == "coarse" else 0) + 7) // 8            # chunks per tap actually read (<= pitch:
+    cu1 = (max(Cs, ich + 1 if where == "skip" else 0) + 7) // 8              # a map may be padded to a 128-byte pitch)
+    assert cu0 <= cc0 and cu1 <= cc1
+    # skip part: plain 3x3 taps on the fine grid (the same for every parity)
+    w1 = torch.zeros(N, 3, 3, cu1 * 8, dtype=torch.float64)
+    w1[..., :Cs] = wc64[:, Cu:].permute(0, 2, 3, 1)
+    if where == "skip":
+        w1[..., ich] = torch.einsum("nukl,u->nkl", wc64[:, :Cu], bt64)
+    kt1 = ((np.arange(3)[:, None] * skip.Wp + np.arange(3)[None, :]).reshape(-1)[:, None] * cc1
+           + np.arange(cu1)[None, :]).reshape(-1).astype(np.int64) | (1 << 31)
+    kt0 = ((np.arange(nth)[:, None] * coarse.Wp + np.arange(ntw)[None, :]).reshape(-1)[:, None] * cc0
+           + np.arange(cu0)[None, :]).reshape(-1).astype(np.int64)
+    w2 = []
+    for ph in range(sh):
+        dh_min = (ph - 1) // sh
+        for pw in range(sw):
+            dw_min = (pw - 1) // sw
+            w0 = torch.zeros(N, nth, ntw, cu0 * 8, dtype=torch.float64)
+            for kh in range(3):
+                for kw in range(3):
+                    r, c = ph + kh - 1, pw + kw - 1
+                    ti, tj = r // sh - dh_min, c // sw - dw_min
+                    w0[:, ti, tj, :Cb] += torch.einsum("nu,bu->nb", wc64[:, :Cu, kh, kw], wt64[:, :, r % sh, c % sw])
+                    if where == "coarse":
+                        w0[:, ti, tj, ich] += wc64[:, :Cu, kh, kw] @ bt64
+            w2.append(torch.cat([w0.reshape(N, -1), w1.reshape(N, -1)], 1))
+    # rows = coarse pixels (h, w); batch z = ph * sw + pw.  First coarse tap of parity (0, 0) is (h - 1, w - 1); a row
+    # parity moves every operand down one (coarse / fine) row, a column parity one pixel to the right.
+    c0_0 = ((coarse.PH - 1) * coarse.Wp + coarse.PW - 1) * cc0
+    c0_1 = ((skip.PH - 1) * skip.Wp + skip.PW - 1) * cc1
+    o_c0 = (dst.PH * dst.Wp + dst.PW) * Ct
+    plan = GemmPlan(
+        M=coarse.B * coarse.H * coarse.W, N=N, w2=torch.stack(w2).float(), ktab=np.concatenate([kt0, kt1]),
+        sources=[Source(coarse.Hp * coarse.Wp * cc0, coarse.Wp * cc0, cc0, c0_0, sZ=coarse.Wp * cc0, sZ2=cc0 if sw == 2 else 0),
+                 Source(skip.Hp * skip.Wp * cc1, sh * skip.Wp * cc1, sw * cc1, c0_1, sZ=skip.Wp * cc1, sZ2=cc1 if sw == 2 else 0)],
+        Hg=coarse.H, Wg=coarse.W, window=(0, coarse.H, 0, coarse.W), halo_zero=False,
+        out=(dst.Hp * dst.Wp * Ct, sh * dst.Wp * Ct, sw * Ct, o_c0), o_sZ=dst.Wp * Ct, o_sZ2=Ct if sw == 2 else 0,
+        nz=sh * sw, nz_lo=sw, z_inner=True, bias=bc, bias_sZ=0, act="leaky", slope=slope, device=device)
+    plans = [plan]
+    flops = 2.0 * dst.B * dst.H * dst.W * N * (nth * ntw * Cb + 9 * Cs + (nth * ntw if where == "coarse" else 9))
+    return PlanGroup(plans, flops)
+
+
 # ------------------------------------------------------------------------------------------ CPU replay
 def replay_on_cpu(plan: GemmPlan, A0: torch.Tensor, A1: Optional[torch.Tensor], out_numel: int,
                   resid: Optional[torch.Tensor] = None, out_init: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -443,7 +541,8 @@ def replay_on_cpu(plan: GemmPlan, A0: torch.Tensor, A1: Optional[torch.Tensor], 
             ok = d.h0 <= h_ < d.h1 and d.w0 <= w_ < d.w1
             if not ok and not d.halo_zero:
                 continue
-            orow = b_ * d.o_sB + h_ * d.o_sH + w_ * d.o_sW + d.o_c0 + d.o_sZ * z
+            zh, zw = (z // d.nz_lo, z % d.nz_lo) if d.nz_lo > 1 else (z, 0)
+            orow = b_ * d.o_sB + h_ * d.o_sH + w_ * d.o_sW + d.o_c0 + d.o_sZ * zh + d.o_sZ2 * zw
             cols = np.arange(d.N)
             qn = cols // d.n_div
             hi = (qn // d.n_sub) * d.o_sNhh + (qn % d.n_sub) * d.o_sNhi if d.n_sub > 1 else qn * d.o_sNhi
@@ -454,7 +553,7 @@ def replay_on_cpu(plan: GemmPlan, A0: torch.Tensor, A1: Optional[torch.Tensor], 
             row = np.empty(d.Ktot, dtype=np.float32)
             for c in range(d.Ktot // 8):
                 s = sel[c]
-                rb = b_ * d.a_sB[s] + h_ * d.a_sH[s] + w_ * d.a_sW[s] + d.a_c0[s] + d.a_sZ[s] * z
+                rb = b_ * d.a_sB[s] + h_ * d.a_sH[s] + w_ * d.a_sW[s] + d.a_c0[s] + d.a_sZ[s] * zh + d.a_sZ2[s] * zw
                 a = (rb + off[c]) * 8
                 row[c * 8:(c + 1) * 8] = srcs[s][a:a + 8]
             v = W[z, :d.N] @ row

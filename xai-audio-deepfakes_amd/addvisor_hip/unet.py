@@ -23,14 +23,31 @@ def _fold_bn(sd, conv: str, bn: str) -> Tuple[torch.Tensor, torch.Tensor]:
     return w * s.view(-1, 1, 1, 1), (b - sd[bn + ".running_mean"].float()) * s + sd[bn + ".bias"].float()
 
 
+def reference_flops(B: int, H: int, W: int) -> float:
+    """2 x MACs of addvisor.py:31-60 on a ``B x 1 x H x W`` input (convolutions, transposed convolutions, 1x1 head)."""
+    def conv(h, w, cin, cout, taps):
+        return 2.0 * B * h * w * cin * cout * taps
+    f = conv(H // 2, W, 1, 32, 15) + conv(H // 2, W, 32, 32, 9)
+    f += conv(H // 4, W, 32, 64, 15) + conv(H // 4, W, 64, 64, 9)
+    f += conv(H // 8, W // 2, 64, 128, 9) + conv(H // 8, W // 2, 128, 128, 9)
+    f += conv(H // 16, W // 4, 128, 256, 9) + conv(H // 16, W // 4, 256, 256, 9)
+    f += conv(H // 16, W // 4, 256, 512, 9) + conv(H // 16, W // 4, 512, 512, 9)
+    f += conv(H // 16, W // 4, 512, 256, 4) + conv(H // 8, W // 2, 384, 256, 9) + conv(H // 8, W // 2, 256, 256, 9)
+    f += conv(H // 8, W // 2, 256, 128, 4) + conv(H // 4, W, 192, 128, 9) + conv(H // 4, W, 128, 128, 9)
+    f += conv(H // 4, W, 128, 64, 2) + conv(H // 2, W, 96, 64, 9) + conv(H // 2, W, 64, 64, 9)
+    f += conv(H // 2, W, 64, 32, 2) + conv(H, W, 33, 32, 9) + conv(H, W, 32, 32, 9)
+    return f + conv(H, W, 32, 1, 1)
+
+
 class HipUNet:
     """``forward(mag [B, F>=H, T>=W] fp32) -> mask [B, H, W] fp32`` (H % 16 == 0, W % 4 == 0)."""
 
-    def __init__(self, sd: Dict[str, torch.Tensor], device, line_tile: bool = True):
+    def __init__(self, sd: Dict[str, torch.Tensor], device, line_tile: bool = True, fuse_up: bool = True):
         """``line_tile``: run the 3x3 32- / 64-channel same-geometry layers on the weights-in-LDS kernel
-        (``advh_conv_taps2d_f16``) instead of the implicit GEMM."""
+        (``advh_conv_taps2d_f16``) instead of the implicit GEMM.  ``fuse_up``: fold every ConvTranspose2d into the
+        convolution that follows it (``gemm.plan_upconv2d``) so the up-sampled maps are never written."""
         _lib.init()
-        self.dev, self.line_tile = device, line_tile
+        self.dev, self.line_tile, self.fuse_up = device, line_tile, fuse_up
         self.sd = {k.replace("module.", ""): v.detach() for k, v in sd.items()}     # LMAC_metrics.py:23-25
         w, b = _fold_bn(self.sd, "e1.block.0", "e1.block.1")
         self.stem_w = w.reshape(32, 15).contiguous().to(device)
@@ -47,6 +64,8 @@ class HipUNet:
             raise ValueError("U-Net input needs H % 16 == 0 and W % 4 == 0 (SURVEY.md D2)")
         dev, sd = self.dev, self.sd
         F = lambda h, w, c, ph, pw: G.FMap(B, h, w, c, ph, pw).alloc(dev)
+        if self.fuse_up:
+            return self._workspace_fused(B, H, W)
         m = dict(
             x1a=F(H // 2, W, 32, 2, 1), x1=F(H // 2, W, 32, 2, 1),
             x2a=F(H // 4, W, 64, 1, 1), x2=F(H // 4, W, 64, 1, 1),
@@ -96,8 +115,64 @@ class HipUNet:
         block(["u1"], "y1a", "y1", "d1")
         ws = dict(maps=m, steps=steps, mask=torch.empty(B, H, W, dtype=torch.float32, device=dev),
                   logits=torch.empty(B, H, W, dtype=torch.float32, device=dev))
-        ws["flops"] = sum(s[0].flops for s in steps) + 2.0 * B * (H // 2) * W * 32 * 15 + 2.0 * B * H * W * 32
+        ws["flops"] = reference_flops(B, H, W)
         self._ws[key] = ws
+        return ws
+
+    def _workspace_fused(self, B: int, H: int, W: int) -> dict:
+        """Same network with up4+d4, up3+d3, up2+d2, up1+d1 as fused launches: the maps u4..u1 do not exist.  The coarse
+        maps b2 / y4 / y3 carry one extra 8-channel chunk whose first channel is the in-image indicator (and unused
+        channels up to the next multiple of 64, so every pixel starts on a 128-byte line); for d1 the
+        indicator rides in the 8-channel spectrogram map ``xin`` = (x, 1, 0, ...) that ``advh_unet_pack_x`` fills."""
+        dev, sd = self.dev, self.sd
+        F = lambda h, w, c, ph, pw: G.FMap(B, h, w, c, ph, pw).alloc(dev)
+        m = dict(
+            x1a=F(H // 2, W, 32, 2, 1), x1=F(H // 2, W, 32, 2, 1),
+            x2a=F(H // 4, W, 64, 1, 1), x2=F(H // 4, W, 64, 1, 1),
+            x3a=F(H // 8, W // 2, 128, 1, 1), x3=F(H // 8, W // 2, 128, 1, 1),
+            x4a=F(H // 16, W // 4, 256, 1, 1), x4=F(H // 16, W // 4, 256, 2, 2),
+            b1=F(H // 16, W // 4, 512, 4, 4), b2=G.add_indicator(F(H // 16, W // 4, 576, 1, 1), 512),
+            y4a=F(H // 8, W // 2, 256, 1, 1), y4=G.add_indicator(F(H // 8, W // 2, 320, 1, 1), 256),
+            y3a=F(H // 4, W, 128, 1, 1), y3=G.add_indicator(F(H // 4, W, 192, 1, 1), 128),
+            y2a=F(H // 2, W, 64, 1, 1), y2=F(H // 2, W, 64, 1, 1),
+            xin=G.add_indicator(F(H, W, 8, 1, 1), 1), y1a=F(H, W, 32, 1, 1), y1=F(H, W, 32, 1, 1),
+        )
+        steps = []
+
+        def conv(srcs, dst, conv_name, bn_name, **kw):
+            w, b = _fold_bn(sd, conv_name, bn_name)
+            if self.line_tile and G.taps2d_supported([m[s] for s in srcs], m[dst], w, **kw):
+                plan = G.Taps2dPlan(m[srcs[0]], m[dst], w, b, slope=SLOPE, device=dev)
+            else:
+                plan = G.plan_conv2d([m[s] for s in srcs], m[dst], w, b, slope=SLOPE, device=dev, **kw)
+            steps.append((plan, srcs, dst))
+
+        def block(srcs, mid, dst, name, **first):
+            conv(srcs, mid, f"{name}.block.0", f"{name}.block.1", **first)
+            conv([mid], dst, f"{name}.block.3", f"{name}.block.4")
+
+        def up_block(coarse, skip, mid, dst, up_name, name, stride, coarse_C, skip_C, indicator):
+            wc, bc = _fold_bn(sd, f"{name}.block.0", f"{name}.block.1")
+            plan = G.plan_upconv2d(m[coarse], m[skip], m[mid], sd[up_name + ".weight"].float(), sd[up_name + ".bias"].float(),
+                                   wc, bc, stride=stride, coarse_C=coarse_C, skip_C=skip_C, indicator=indicator,
+                                   slope=SLOPE, device=dev)
+            steps.append((plan, [coarse, skip], mid))
+            conv([mid], dst, f"{name}.block.3", f"{name}.block.4")
+
+        conv(["x1a"], "x1", "e1.block.3", "e1.block.4")
+        block(["x1"], "x2a", "x2", "e2", stride=(2, 1), padding=(2, 1))
+        block(["x2"], "x3a", "x3", "e3", stride=(2, 2))
+        block(["x3"], "x4a", "x4", "e4", stride=(2, 2))
+        conv(["x4"], "b1", "bottleneck.0", "bottleneck.1", padding=(2, 2), dilation=(2, 2))
+        conv(["b1"], "b2", "bottleneck.3", "bottleneck.4", padding=(4, 4), dilation=(4, 4))
+        up_block("b2", "x3", "y4a", "y4", "up4", "d4", (2, 2), 512, 128, ("coarse", 512))
+        up_block("y4", "x2", "y3a", "y3", "up3", "d3", (2, 2), 256, 64, ("coarse", 256))
+        up_block("y3", "x1", "y2a", "y2", "up2", "d2", (2, 1), 128, 32, ("coarse", 128))
+        up_block("y2", "xin", "y1a", "y1", "up1", "d1", (2, 1), 64, 1, ("skip", 1))
+        ws = dict(maps=m, steps=steps, mask=torch.empty(B, H, W, dtype=torch.float32, device=dev),
+                  logits=torch.empty(B, H, W, dtype=torch.float32, device=dev))
+        ws["flops"] = reference_flops(B, H, W)                # the reference formulation's count, not the fused launches'
+        self._ws[(B, H, W)] = ws
         return ws
 
     def flops(self, B: int, H: int, W: int) -> float:
@@ -115,10 +190,11 @@ class HipUNet:
         ws = self._workspace(B, H, W)
         m, lib = ws["maps"], _lib.lib()
         st = torch.cuda.current_stream().cuda_stream
-        x1a, u1 = m["x1a"], m["u1"]
+        x1a = m["x1a"]
+        xcat, xc0 = (m["xin"], 0) if self.fuse_up else (m["u1"], 32)
         _lib.check(lib.advh_unet_stem(mag.data_ptr(), Fq, Tq, B, H, W, self.stem_w.data_ptr(), self.stem_b.data_ptr(),
                                       x1a.t.data_ptr(), x1a.PH, x1a.PW, SLOPE, st), "advh_unet_stem")
-        _lib.check(lib.advh_unet_pack_x(mag.data_ptr(), Fq, Tq, B, H, W, u1.t.data_ptr(), u1.C, 32, u1.PH, u1.PW, st),
+        _lib.check(lib.advh_unet_pack_x(mag.data_ptr(), Fq, Tq, B, H, W, xcat.t.data_ptr(), xcat.C, xc0, xcat.PH, xcat.PW, st),
                    "advh_unet_pack_x")
         for plan, srcs, dst in ws["steps"]:
             a0 = m[srcs[0]].t

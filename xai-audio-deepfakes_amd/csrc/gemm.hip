@@ -125,7 +125,8 @@ __device__ __forceinline__ void epilogue_store(const advh_gemm_desc& p, float (&
 }
 
 template <int MI, int NI>
-__device__ __forceinline__ void gemm_epilogue(const advh_gemm_desc& p, f32x4 (&acc)[NI][MI], int mw0, int nw0, int fr, int fq, int z) {
+__device__ __forceinline__ void gemm_epilogue(const advh_gemm_desc& p, f32x4 (&acc)[NI][MI], int mw0, int nw0, int fr, int fq, int z,
+                                              long zo = -1) {          // zo: output offset of batch z (default o_sZ * z)
     static_assert(NI % 2 == 0, "the wide epilogue pairs n-tiles");
     const float* bias = p.bias ? p.bias + (long)p.bias_sZ * z : nullptr;
     const RowDecomp rd(p.Wg, p.Hg);
@@ -137,7 +138,7 @@ __device__ __forceinline__ void gemm_epilogue(const advh_gemm_desc& p, f32x4 (&a
         rd(m, b, h, w);
         bool ok = (int)h >= p.h0 && (int)h < p.h1 && (int)w >= p.w0 && (int)w < p.w1;
         if (!ok && !p.halo_zero) continue;
-        long orow = (long)b * p.o_sB + (long)h * p.o_sH + (long)w * p.o_sW + p.o_c0 + p.o_sZ * z;
+        long orow = (long)b * p.o_sB + (long)h * p.o_sH + (long)w * p.o_sW + p.o_c0 + (zo >= 0 ? zo : p.o_sZ * z);
         if (p.wide) {
 #pragma unroll
             for (int q = 0; q < NI / 2; ++q) {
@@ -190,11 +191,17 @@ __global__ __launch_bounds__(64 * WM * WN, WPE) void gemm_f16_kernel(const advh_
 
     // XCD-aware tile order: workgroups that share an XCD (id % 8) walk neighbouring tiles
     const int tilesN = (p.N + BN - 1) / BN;
-    const int nwg = gridDim.x;
+    int nwg = gridDim.x;
     int id = blockIdx.x;
     {
         const int q8 = nwg / 8, r8 = nwg % 8, xcd = id % 8;
         id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + id / 8;
+    }
+    int z = blockIdx.z;
+    if (p.z_inner) {                                     // batches of one tile next to each other on one XCD
+        z = id % p.nz;
+        id /= p.nz;
+        nwg /= p.nz;
     }
     // super-columns: walk all M tiles of `sc` N-tiles before moving on, so the weight slice in flight (sc*BN*K*2
     // bytes) stays L2-resident instead of cycling a > 4 MiB weight through every XCD's L2 (host picks sc; 0 = off)
@@ -207,10 +214,10 @@ __global__ __launch_bounds__(64 * WM * WN, WPE) void gemm_f16_kernel(const advh_
         tile_n = s * sc + rem - tile_m * wcols;
     }
     const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int z = blockIdx.z;
+    const int zh = p.nz_lo > 1 ? z / p.nz_lo : z, zw = p.nz_lo > 1 ? z % p.nz_lo : 0;
 
-    const _Float16* A0 = (const _Float16*)p.A0 + p.a_sZ[0] * z * 8;
-    const _Float16* A1 = (const _Float16*)p.A1 + p.a_sZ[1] * z * 8;
+    const _Float16* A0 = (const _Float16*)p.A0 + (p.a_sZ[0] * zh + p.a_sZ2[0] * zw) * 8;
+    const _Float16* A1 = (const _Float16*)p.A1 + (p.a_sZ[1] * zh + p.a_sZ2[1] * zw) * 8;
     const _Float16* Wp = (const _Float16*)p.W + p.w_sZ * z;
 
     // ---- loader setup: this thread's chunk column q and its NA rows' base offsets (chunk units)
@@ -288,14 +295,16 @@ __global__ __launch_bounds__(64 * WM * WN, WPE) void gemm_f16_kernel(const advh_
         __syncthreads();
     }
 
-    gemm_epilogue<MI, NI>(p, acc, m0 + wm * TM, n0 + wn * TN, fr, fq, z);
+    gemm_epilogue<MI, NI>(p, acc, m0 + wm * TM, n0 + wn * TN, fr, fq, z, p.o_sZ * zh + p.o_sZ2 * zw);
 }
 
 template <int BM, int BN, int WM, int WN, int WPE>
 static int launch(const advh_gemm_desc& d, hipStream_t s) {
     const int tilesM = (d.M + BM - 1) / BM, tilesN = (d.N + BN - 1) / BN;
     if (tilesN * BN > d.w_rows) return ADVH_EINVAL;
-    dim3 grid(tilesM * tilesN, 1, d.nz > 0 ? d.nz : 1);
+    const int nz = d.nz > 0 ? d.nz : 1;
+    if (d.z_inner && (long)tilesM * tilesN * nz > 0x7fffffffL) return ADVH_EINVAL;
+    dim3 grid(d.z_inner ? tilesM * tilesN * nz : tilesM * tilesN, 1, d.z_inner ? 1 : nz);
     hipLaunchKernelGGL((gemm_f16_kernel<BM, BN, WM, WN, WPE>), grid, dim3(64 * WM * WN), 0, s, d);
     return ADVH_LAUNCH_CHECK();
 }
@@ -802,6 +811,10 @@ extern "C" int advh_gemm_f16(const advh_gemm_desc* d, int tile, advh_stream_t st
     hipStream_t s = (hipStream_t)stream;
     // same rule as addvisor_hip/gemm.py pick_tile
     if (tile == ADVH_TILE_AUTO) tile = d->N > 64 ? ADVH_TILE_128x128 : (d->N > 32 ? ADVH_TILE_256x64 : ADVH_TILE_256x32);
+    if (d->nz_lo < 0 || (d->nz_lo > 1 && (d->nz <= 0 || d->nz % d->nz_lo))) return ADVH_EINVAL;
+    if ((d->nz_lo > 1 || d->z_inner) && (tile == ADVH_TILE_256x256 || tile == ADVH_TILE_256x256_RING || tile == ADVH_TILE_256x128 ||
+                                          tile == ADVH_TILE_256x128_PERSIST || tile == ADVH_TILE_256x256_W4))
+        return ADVH_EUNSUPPORTED;                        // the two-level batch lives in gemm_f16_kernel only
     switch (tile) {
         case ADVH_TILE_128x128: return launch<128, 128, 2, 2, 3>(*d, s);
         case ADVH_TILE_256x64: return launch<256, 64, 4, 1, 3>(*d, s);

@@ -51,7 +51,9 @@ __global__ __launch_bounds__(256) void unet_stem_kernel(const float* __restrict_
     }
 }
 
-// channels [c0, c0+8) of the d1 skip-concat buffer <- (x, 0, 0, 0, 0, 0, 0, 0)   (torch.cat([y1, x]), addvisor.py:79)
+// channels [c0, c0+8) of the d1 skip-concat buffer <- (x, 1, 0, 0, 0, 0, 0, 0)   (torch.cat([y1, x]), addvisor.py:79).
+// The 1 is the in-image indicator of the fused up-convolution (zero in the halo, which is never written); the unfused
+// path pairs that channel with zero weights.
 __global__ __launch_bounds__(256) void unet_pack_x_kernel(const float* __restrict__ mag, int Fq, int Tq, int H, int W,
                                                           _Float16* __restrict__ cat, int C, int c0, int PH, int PW, long total) {
     long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -59,7 +61,7 @@ __global__ __launch_bounds__(256) void unet_pack_x_kernel(const float* __restric
     int w = (int)(i % W);
     long r = i / W;
     int h = (int)(r % H), b = (int)(r / H);
-    f16x8 v = {(_Float16)mag[((long)b * Fq + h) * Tq + w], 0, 0, 0, 0, 0, 0, 0};
+    f16x8 v = {(_Float16)mag[((long)b * Fq + h) * Tq + w], (_Float16)1.0f, 0, 0, 0, 0, 0, 0};
     *(f16x8*)(cat + (((long)b * (H + 2 * PH) + h + PH) * (W + 2 * PW) + w + PW) * C + c0) = v;
 }
 
