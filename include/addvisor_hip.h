@@ -331,6 +331,26 @@ typedef struct advh_taps2d_desc {
     float slope;
 } advh_taps2d_desc;
 int advh_conv_taps2d_f16(const advh_taps2d_desc* d, int C, advh_stream_t stream);
+/* Last decoder stage of the U-Net as ONE line-tile launch: up1 = ConvTranspose2d(64,32,(2,1),stride (2,1)) folded into
+ * d1.block.0 = Conv2d(33,32,3,padding 1) + BatchNorm + LeakyReLU (addvisor.py:53-54,78-80).
+ *   Xc  coarse map  [B][Hc+2PHc][W_+2PWc][64]  fp16, zero halo (PHc, PWc >= 1)              (y2)
+ *   Xs  skip map    [B][2Hc+2PHs][W_+2PWs][8]  fp16 = (spectrogram, in-image indicator, 0 x6), zero halo (advh_unet_pack_x)
+ *   W   fp16 [2 row parities][15 k-steps][32 rows][32]: per parity the composed weights in the K order
+ *       (coarse tap t = 3 ti + tj: 64 channels) x 6, (fine tap kh*3 + kw: 8 channels) x 9, zero-padded 456 -> 480;
+ *       row R of a k-step carries output channel 8 ((R>>2)&3) + 4 ((R>>4)&1) + (R&3)
+ *   out_h [B][2Hc+2PHo][W_+2PWo][32] fp16, interior written (halo must already be zero); Hc % 8 == 0.            */
+typedef struct advh_upconv_desc {
+    const void* Xc;
+    const void* Xs;
+    const void* W;
+    const float* bias;    /* [32] or NULL */
+    void* out_h;
+    int B, Hc, W_, PHc, PWc, PHs, PWs, PHo, PWo;
+    int act;              /* ADVH_ACT_NONE | ADVH_ACT_LEAKY */
+    float slope;
+} advh_upconv_desc;
+int advh_upconv21_tile_f16(const advh_upconv_desc* d, advh_stream_t stream);
+int advh_upconv21_tile_lds_bytes(void);
 int advh_conv_taps_tile(int C, int ntap, int span);       /* positions per workgroup tile (128/192/256); 0 = does not fit */
 int advh_conv_taps_lds_bytes(int C, int ntap, int span);  /* weights + two line buffers; -1 = does not fit           */
 int advh_conv_taps_f16(const advh_taps_desc* d, int C, advh_stream_t stream);

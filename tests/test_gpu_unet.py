@@ -49,7 +49,7 @@ def test_unet_small(gpu_device, shape, golden):
         assert (mask.cpu() - torch.from_numpy(golden("unet.npz")["out_a"])[:, 0]).abs().max().item() <= TOL_MASK
 
 
-@pytest.mark.parametrize("shape", [(2, 32, 8), (2, 64, 20)])
+@pytest.mark.parametrize("shape", [(2, 32, 8), (2, 64, 20), (1, 48, 36)])
 def test_unet_fused_up_matches_unfused(gpu_device, shape):
     """``fuse_up`` (ConvTranspose2d folded into the following Conv2d, gemm.plan_upconv2d) against the layer-by-layer
     path and the oracle, with the transposed convolutions' biases scaled up so the border handling of the bias
@@ -63,11 +63,13 @@ def test_unet_fused_up_matches_unfused(gpu_device, shape):
     ref = unet_ref.unet_forward(x, sd)[:, 0]
     fused = HipUNet(sd, gpu_device, fuse_up=True).forward(x[:, 0].to(gpu_device), H=H, W=W)
     plain = HipUNet(sd, gpu_device, fuse_up=False).forward(x[:, 0].to(gpu_device), H=H, W=W)
+    gemm_only = HipUNet(sd, gpu_device, fuse_up=True, line_tile=False).forward(x[:, 0].to(gpu_device), H=H, W=W)
     check(fused, ref)
     check(plain, ref)
-    d = (fused - plain).abs().max().item()
-    print(f"fused vs layer-by-layer: max {d:.3e}")
-    assert d <= 4e-3
+    check(gemm_only, ref)
+    d, d2 = (fused - plain).abs().max().item(), (fused - gemm_only).abs().max().item()
+    print(f"fused vs layer-by-layer: max {d:.3e}; line-tile (incl. advh_upconv21_tile_f16) vs implicit-GEMM fused: max {d2:.3e}")
+    assert d <= 4e-3 and d2 <= 4e-3
 
 
 def test_unet_full_size(gpu_device, golden):

@@ -445,6 +445,40 @@ def add_indicator(f: FMap, channel: int) -> FMap:
     return f
 
 
+def compose_upconv_weights(wt: torch.Tensor, bt: torch.Tensor, wc: torch.Tensor, stride, indicator: Tuple[str, int]):
+    """Composed fp64 weights of ``conv3x3(cat([ConvTranspose2d(coarse), skip]))`` per output parity class (see
+    ``plan_upconv2d``): returns ``([N, K] per class z = ph * sw + pw, cu0, cu1)`` with K = (coarse taps x 8 cu0 channels,
+    then the 9 fine taps x 8 cu1 channels); ``cu0`` / ``cu1`` = 16-byte chunks read per coarse / fine tap."""
+    sh, sw = stride
+    Cb, Cu = wt.shape[:2]
+    N, Cs = wc.shape[0], wc.shape[1] - Cu
+    where, ich = indicator
+    assert where in ("coarse", "skip") and ich >= (Cb if where == "coarse" else Cs)
+    wt64, wc64, bt64 = wt.double(), wc.double(), bt.double()
+    nth, ntw = 2, (2 if sw == 2 else 3)
+    cu0 = (max(Cb, ich + 1 if where == "coarse" else 0) + 7) // 8
+    cu1 = (max(Cs, ich + 1 if where == "skip" else 0) + 7) // 8
+    w1 = torch.zeros(N, 3, 3, cu1 * 8, dtype=torch.float64)           # skip part: plain 3x3 taps, the same for every parity
+    w1[..., :Cs] = wc64[:, Cu:].permute(0, 2, 3, 1)
+    if where == "skip":
+        w1[..., ich] = torch.einsum("nukl,u->nkl", wc64[:, :Cu], bt64)
+    w2 = []
+    for ph in range(sh):
+        dh_min = (ph - 1) // sh
+        for pw in range(sw):
+            dw_min = (pw - 1) // sw
+            w0 = torch.zeros(N, nth, ntw, cu0 * 8, dtype=torch.float64)
+            for kh in range(3):
+                for kw in range(3):
+                    r, c = ph + kh - 1, pw + kw - 1
+                    ti, tj = r // sh - dh_min, c // sw - dw_min
+                    w0[:, ti, tj, :Cb] += torch.einsum("nu,bu->nb", wc64[:, :Cu, kh, kw], wt64[:, :, r % sh, c % sw])
+                    if where == "coarse":
+                        w0[:, ti, tj, ich] += wc64[:, :Cu, kh, kw] @ bt64
+            w2.append(torch.cat([w0.reshape(N, -1), w1.reshape(N, -1)], 1))
+    return w2, cu0, cu1
+
+
 def plan_upconv2d(coarse: FMap, skip: FMap, dst: FMap, wt: torch.Tensor, bt: torch.Tensor, wc: torch.Tensor,
                   bc: torch.Tensor, *, stride, coarse_C: int, skip_C: int, indicator: Tuple[str, int],
                   slope: float = 0.2, device=None) -> PlanGroup:
@@ -469,37 +503,15 @@ def plan_upconv2d(coarse: FMap, skip: FMap, dst: FMap, wt: torch.Tensor, bt: tor
     assert coarse_C == Cb and skip_C == Cs and coarse.C >= Cb and skip.C >= Cs and coarse.C % 8 == 0 and skip.C % 8 == 0
     assert (dst.H, dst.W) == (coarse.H * sh, coarse.W * sw) == (skip.H, skip.W) and dst.B == coarse.B == skip.B
     assert coarse.PH >= 1 and coarse.PW >= 1 and skip.PH >= 1 and skip.PW >= 1 and dst.C % 8 == 0
-    where, ich = indicator
-    assert where in ("coarse", "skip") and ich >= (Cb if where == "coarse" else Cs)
-    wt64, wc64, bt64 = wt.double(), wc.double(), bt.double()
     nth, ntw = 2, (2 if sw == 2 else 3)
     cc0, cc1, Ct = coarse.C // 8, skip.C // 8, dst.C                       # pixel pitch of the maps in chunks
-    cu0 = (max(Cb, ich + 1 if where == "coarse" else 0) + 7) // 8            # chunks per tap actually read (<= pitch:
-    cu1 = (max(Cs, ich + 1 if where == "skip" else 0) + 7) // 8              # a map may be padded to a 128-byte pitch)
-    assert cu0 <= cc0 and cu1 <= cc1
-    # skip part: plain 3x3 taps on the fine grid (the same for every parity)
-    w1 = torch.zeros(N, 3, 3, cu1 * 8, dtype=torch.float64)
-    w1[..., :Cs] = wc64[:, Cu:].permute(0, 2, 3, 1)
-    if where == "skip":
-        w1[..., ich] = torch.einsum("nukl,u->nkl", wc64[:, :Cu], bt64)
+    w2, cu0, cu1 = compose_upconv_weights(wt, bt, wc, stride, indicator)    # cu: chunks per tap actually read (<= pitch:
+    assert cu0 <= cc0 and cu1 <= cc1                                        # a map may be padded to a 128-byte pitch)
+    where = indicator[0]
     kt1 = ((np.arange(3)[:, None] * skip.Wp + np.arange(3)[None, :]).reshape(-1)[:, None] * cc1
            + np.arange(cu1)[None, :]).reshape(-1).astype(np.int64) | (1 << 31)
     kt0 = ((np.arange(nth)[:, None] * coarse.Wp + np.arange(ntw)[None, :]).reshape(-1)[:, None] * cc0
            + np.arange(cu0)[None, :]).reshape(-1).astype(np.int64)
-    w2 = []
-    for ph in range(sh):
-        dh_min = (ph - 1) // sh
-        for pw in range(sw):
-            dw_min = (pw - 1) // sw
-            w0 = torch.zeros(N, nth, ntw, cu0 * 8, dtype=torch.float64)
-            for kh in range(3):
-                for kw in range(3):
-                    r, c = ph + kh - 1, pw + kw - 1
-                    ti, tj = r // sh - dh_min, c // sw - dw_min
-                    w0[:, ti, tj, :Cb] += torch.einsum("nu,bu->nb", wc64[:, :Cu, kh, kw], wt64[:, :, r % sh, c % sw])
-                    if where == "coarse":
-                        w0[:, ti, tj, ich] += wc64[:, :Cu, kh, kw] @ bt64
-            w2.append(torch.cat([w0.reshape(N, -1), w1.reshape(N, -1)], 1))
     # rows = coarse pixels (h, w); batch z = ph * sw + pw.  First coarse tap of parity (0, 0) is (h - 1, w - 1); a row
     # parity moves every operand down one (coarse / fine) row, a column parity one pixel to the right.
     c0_0 = ((coarse.PH - 1) * coarse.Wp + coarse.PW - 1) * cc0
@@ -515,6 +527,58 @@ def plan_upconv2d(coarse: FMap, skip: FMap, dst: FMap, wt: torch.Tensor, bt: tor
     plans = [plan]
     flops = 2.0 * dst.B * dst.H * dst.W * N * (nth * ntw * Cb + 9 * Cs + (nth * ntw if where == "coarse" else 9))
     return PlanGroup(plans, flops)
+
+
+class UpconvDesc(C.Structure):
+    _fields_ = [("Xc", C.c_void_p), ("Xs", C.c_void_p), ("W", C.c_void_p), ("bias", C.c_void_p), ("out_h", C.c_void_p),
+                ("B", C.c_int), ("Hc", C.c_int), ("W_", C.c_int), ("PHc", C.c_int), ("PWc", C.c_int), ("PHs", C.c_int),
+                ("PWs", C.c_int), ("PHo", C.c_int), ("PWo", C.c_int), ("act", C.c_int), ("slope", C.c_float)]
+
+
+def upconv_tile_supported(coarse: FMap, skip: FMap, dst: FMap, wt: torch.Tensor, wc: torch.Tensor, stride, indicator) -> bool:
+    """Geometry of ``advh_upconv21_tile_f16``: up1 + d1.block.0 of the U-Net (64 coarse channels, 8-channel skip map
+    carrying the indicator in channel 1, 32 outputs, stride (2, 1))."""
+    return (tuple(stride) == (2, 1) and tuple(wt.shape) == (64, 32, 2, 1) and tuple(wc.shape) == (32, 33, 3, 3)
+            and coarse.C == 64 and skip.C == 8 and dst.C == 32 and tuple(indicator) == ("skip", 1) and coarse.H % 8 == 0
+            and min(coarse.PH, coarse.PW, skip.PH, skip.PW) >= 1)
+
+
+class UpconvTilePlan:
+    """up1 + d1.block.0 as one LDS line-tile launch (csrc/upconv_tile.hip); same ``run`` signature as a GemmPlan."""
+
+    def __init__(self, coarse: FMap, skip: FMap, dst: FMap, wt: torch.Tensor, bt: torch.Tensor, wc: torch.Tensor,
+                 bc: torch.Tensor, *, slope: float = 0.2, device=None):
+        assert upconv_tile_supported(coarse, skip, dst, wt, wc, (2, 1), ("skip", 1))
+        w2, cu0, cu1 = compose_upconv_weights(wt, bt, wc, (2, 1), ("skip", 1))
+        assert (cu0, cu1) == (8, 1) and w2[0].shape == (32, 456)
+        R = np.arange(32)
+        ch = 8 * ((R >> 2) & 3) + 4 * ((R >> 4) & 1) + (R & 3)           # MFMA row R carries this output channel
+        wp = torch.zeros(2, 15, 32, 32, dtype=torch.float16)
+        for ph in range(2):
+            full = torch.zeros(32, 480, dtype=torch.float64)
+            full[:, :456] = w2[ph]
+            wp[ph] = full[torch.from_numpy(ch)].reshape(32, 15, 32).permute(1, 0, 2).to(torch.float16)
+        self.w = wp.contiguous().to(device) if device is not None else wp.contiguous()
+        self.bias = bc.to(torch.float32).contiguous()
+        self.bias = self.bias.to(device) if device is not None else self.bias
+        d = UpconvDesc()
+        d.B, d.Hc, d.W_ = coarse.B, coarse.H, coarse.W
+        d.PHc, d.PWc, d.PHs, d.PWs, d.PHo, d.PWo = coarse.PH, coarse.PW, skip.PH, skip.PW, dst.PH, dst.PW
+        d.act, d.slope = ACT["leaky"], slope
+        self.desc = d
+        self.numels = (coarse.t.numel() if coarse.t is not None else 0, skip.t.numel() if skip.t is not None else 0,
+                       dst.t.numel() if dst.t is not None else 0)
+        self.flops = 2.0 * dst.B * dst.H * dst.W * 32 * (6 * 64 + 9 * 2)
+        self.tile = None
+
+    def run(self, A0: torch.Tensor, A1: torch.Tensor, *, out_h: torch.Tensor, stream: Optional[int] = None):
+        d = self.desc
+        for t, n in zip((A0, A1, out_h), self.numels):
+            assert t.dtype == torch.float16 and t.is_cuda and t.is_contiguous() and (n == 0 or t.numel() == n)
+        d.Xc, d.Xs, d.W, d.bias, d.out_h = A0.data_ptr(), A1.data_ptr(), self.w.data_ptr(), self.bias.data_ptr(), out_h.data_ptr()
+        if stream is None:
+            stream = torch.cuda.current_stream().cuda_stream
+        _lib.check(_lib.lib().advh_upconv21_tile_f16(C.byref(d), stream), "advh_upconv21_tile_f16")
 
 
 # ------------------------------------------------------------------------------------------ CPU replay

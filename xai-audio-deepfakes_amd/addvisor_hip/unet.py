@@ -153,9 +153,12 @@ class HipUNet:
 
         def up_block(coarse, skip, mid, dst, up_name, name, stride, coarse_C, skip_C, indicator):
             wc, bc = _fold_bn(sd, f"{name}.block.0", f"{name}.block.1")
-            plan = G.plan_upconv2d(m[coarse], m[skip], m[mid], sd[up_name + ".weight"].float(), sd[up_name + ".bias"].float(),
-                                   wc, bc, stride=stride, coarse_C=coarse_C, skip_C=skip_C, indicator=indicator,
-                                   slope=SLOPE, device=dev)
+            wt, bt = sd[up_name + ".weight"].float(), sd[up_name + ".bias"].float()
+            if self.line_tile and G.upconv_tile_supported(m[coarse], m[skip], m[mid], wt, wc, stride, indicator):
+                plan = G.UpconvTilePlan(m[coarse], m[skip], m[mid], wt, bt, wc, bc, slope=SLOPE, device=dev)
+            else:
+                plan = G.plan_upconv2d(m[coarse], m[skip], m[mid], wt, bt, wc, bc, stride=stride, coarse_C=coarse_C,
+                                       skip_C=skip_C, indicator=indicator, slope=SLOPE, device=dev)
             steps.append((plan, [coarse, skip], mid))
             conv([mid], dst, f"{name}.block.3", f"{name}.block.4")
 
