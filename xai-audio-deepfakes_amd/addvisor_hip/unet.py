@@ -7,6 +7,7 @@ concatenations done by pointer.  The 1-channel stem and the 1x1 mask head are di
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, Optional, Tuple
 
 import torch
@@ -42,11 +43,15 @@ def reference_flops(B: int, H: int, W: int) -> float:
 class HipUNet:
     """``forward(mag [B, F>=H, T>=W] fp32) -> mask [B, H, W] fp32`` (H % 16 == 0, W % 4 == 0)."""
 
-    def __init__(self, sd: Dict[str, torch.Tensor], device, line_tile: bool = True, fuse_up: bool = True):
+    def __init__(self, sd: Dict[str, torch.Tensor], device, line_tile: Optional[bool] = None, fuse_up: Optional[bool] = None):
         """``line_tile``: run the 3x3 32- / 64-channel same-geometry layers on the weights-in-LDS kernel
         (``advh_conv_taps2d_f16``) instead of the implicit GEMM.  ``fuse_up``: fold every ConvTranspose2d into the
         convolution that follows it (``gemm.plan_upconv2d``) so the up-sampled maps are never written."""
         _lib.init()
+        if line_tile is None:                                  # both default on; the environment switches are for A/B measurements
+            line_tile = os.environ.get("ADDVISOR_UNET_LINE_TILE", "1") != "0"
+        if fuse_up is None:
+            fuse_up = os.environ.get("ADDVISOR_UNET_FUSE_UP", "1") != "0"
         self.dev, self.line_tile, self.fuse_up = device, line_tile, fuse_up
         self.sd = {k.replace("module.", ""): v.detach() for k, v in sd.items()}     # LMAC_metrics.py:23-25
         w, b = _fold_bn(self.sd, "e1.block.0", "e1.block.1")

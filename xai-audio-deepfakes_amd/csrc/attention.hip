@@ -15,6 +15,8 @@
 
 namespace advh {
 
+constexpr float LOG2E = 1.4426950408889634f;
+
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -85,7 +87,7 @@ __global__ __launch_bounds__(256, (D <= 64 ? 2 : 1)) void attention_kernel(const
         for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float v = (kt * 16 + g * 4 + r < T) ? s[kt][r] * scale : -INFINITY;
+                float v = (kt * 16 + g * 4 + r < T) ? s[kt][r] * (scale * LOG2E) : -INFINITY;   // log2 domain: exp(x) = v_exp_f32(x log2 e)
                 s[kt][r] = v;
                 mx = fmaxf(mx, v);
             }
@@ -95,7 +97,7 @@ __global__ __launch_bounds__(256, (D <= 64 ? 2 : 1)) void attention_kernel(const
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { float e = expf(s[kt][r] - mx); s[kt][r] = e; sum += e; }
+            for (int r = 0; r < 4; ++r) { float e = __builtin_amdgcn_exp2f(s[kt][r] - mx); s[kt][r] = e; sum += e; }
         sum += __shfl_xor(sum, 16, 64);
         sum += __shfl_xor(sum, 32, 64);
         const float inv = 1.f / sum;
@@ -191,7 +193,7 @@ __global__ __launch_bounds__(256, 2) void attention_tr_kernel(const _Float16* __
         for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float v = (kt * 16 + g * 4 + r < T) ? s[kt][r] * scale : -INFINITY;
+                const float v = (kt * 16 + g * 4 + r < T) ? s[kt][r] * (scale * LOG2E) : -INFINITY;   // log2 domain: exp(x) = v_exp_f32(x log2 e)
                 s[kt][r] = v;
                 mx = fmaxf(mx, v);
             }
@@ -201,7 +203,7 @@ __global__ __launch_bounds__(256, 2) void attention_tr_kernel(const _Float16* __
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { const float e = expf(s[kt][r] - mx); s[kt][r] = e; sum += e; }
+            for (int r = 0; r < 4; ++r) { const float e = __builtin_amdgcn_exp2f(s[kt][r] - mx); s[kt][r] = e; sum += e; }
         sum += __shfl_xor(sum, 16, 64);
         sum += __shfl_xor(sum, 32, 64);
         const float inv = 1.f / sum;

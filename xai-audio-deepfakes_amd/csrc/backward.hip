@@ -13,6 +13,8 @@
 
 namespace advh {
 
+constexpr float LOG2E = 1.4426950408889634f;
+
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -242,7 +244,7 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const _Float16* __re
         for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float v = (kt * 16 + g * 4 + r < T) ? s[kt][r] * scale : -INFINITY;
+                float v = (kt * 16 + g * 4 + r < T) ? s[kt][r] * (scale * LOG2E) : -INFINITY;   // log2 domain: exp(x) = v_exp_f32(x log2 e)
                 s[kt][r] = v;
                 mx = fmaxf(mx, v);
             }
@@ -252,7 +254,7 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const _Float16* __re
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { float e = expf(s[kt][r] - mx); s[kt][r] = e; sum += e; }
+            for (int r = 0; r < 4; ++r) { float e = __builtin_amdgcn_exp2f(s[kt][r] - mx); s[kt][r] = e; sum += e; }
         sum += __shfl_xor(sum, 16, 64);
         sum += __shfl_xor(sum, 32, 64);
         const float inv = 1.f / sum;
@@ -362,7 +364,7 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const _Float16* __re
                     int q = qt * 16 + g * 4 + r;                   // this lane's query rows; its key column = krow
                     float p = 0.f, ds = 0.f;
                     if (qt < NT && q < T && krow < T) {
-                        p = expf(s[r] * scale - rmax[q]) * rinv[q];
+                        p = __builtin_amdgcn_exp2f(s[r] * (scale * LOG2E) - rmax[q]) * rinv[q];   // rmax is kept in the log2 domain
                         ds = p * (dp[r] - rdel[q]) * scale;
                     }
                     pf[half * 4 + r] = (_Float16)p;

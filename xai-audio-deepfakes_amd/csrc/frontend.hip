@@ -41,12 +41,21 @@ __global__ __launch_bounds__(256) void wave_stats_kernel(const float* __restrict
     }
     const float* w = wave + (long)blockIdx.x * stride;
     const int n = n_in < L ? n_in : L;
-    double s = 0;
-    for (int i = threadIdx.x; i < n; i += 256) s += w[i];
-    const double mean = block_sum_d(s, red) / L;
-    double q = 0;
-    for (int i = threadIdx.x; i < n; i += 256) { double d = w[i] - mean; q += d * d; }
-    q = block_sum_d(q, red) + (double)(L - n) * mean * mean;       // zero-padded tail
+    // 16-byte loads with four independent fp64 accumulators (the scalar loop was latency-bound: 129 us for 49 MB)
+    const int n4 = (((unsigned long)w & 15) == 0) ? n / 4 : 0;
+    const float4* w4 = (const float4*)w;
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    for (int i = threadIdx.x; i < n4; i += 256) { const float4 v = w4[i]; s0 += v.x; s1 += v.y; s2 += v.z; s3 += v.w; }
+    for (int i = 4 * n4 + threadIdx.x; i < n; i += 256) s0 += w[i];
+    const double mean = block_sum_d((s0 + s1) + (s2 + s3), red) / L;
+    double q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+    for (int i = threadIdx.x; i < n4; i += 256) {
+        const float4 v = w4[i];
+        const double d0 = v.x - mean, d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
+        q0 += d0 * d0; q1 += d1 * d1; q2 += d2 * d2; q3 += d3 * d3;
+    }
+    for (int i = 4 * n4 + threadIdx.x; i < n; i += 256) { const double d = w[i] - mean; q0 += d * d; }
+    double q = block_sum_d((q0 + q1) + (q2 + q3), red) + (double)(L - n) * mean * mean;       // zero-padded tail
     if (threadIdx.x == 0) {
         float sd = (float)sqrt(q / (L - 1));
         stats[blockIdx.x] = make_float2((float)mean, 1.f / (sd + 1e-7f));
@@ -64,7 +73,6 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
                                                        const float2* __restrict__ stats, const float* __restrict__ w0,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        float2* __restrict__ norm, float2* __restrict__ mr, int T0, int C0) {
-    __shared__ double red[4];
     __shared__ double S[K0 + K0 * K0];
     const int b = blockIdx.x, tid = threadIdx.x;
     const float* w = wave + (long)b * stride;
@@ -87,17 +95,33 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
             for (int j = k; j < K0; ++j) s2[idx++] += (double)x[k] * x[j];
         }
     }
-    {
-        int idx = 0;
+    {   // all 65 sums in ONE exchange: wavefront shuffles, partials to LDS, fixed-order add (was 65 block reductions)
+        __shared__ double part[4][K0 + K0 * (K0 + 1) / 2];
+        const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll
         for (int k = 0; k < K0; ++k) {
-            double v = block_sum_d(s1[k], red);
-            if (tid == 0) S[k] = v / T0;
+            double v = s1[k];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            if (lane == 0) part[wv][k] = v;
         }
-        for (int k = 0; k < K0; ++k)
-            for (int j = k; j < K0; ++j) {
-                double v = block_sum_d(s2[idx++], red);
-                if (tid == 0) { S[K0 + k * K0 + j] = v / T0; S[K0 + j * K0 + k] = v / T0; }
-            }
+#pragma unroll
+        for (int k = 0; k < K0 * (K0 + 1) / 2; ++k) {
+            double v = s2[k];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            if (lane == 0) part[wv][K0 + k] = v;
+        }
+        __syncthreads();
+        if (tid < K0) S[tid] = ((part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid])) / T0;
+        if (tid < K0 * (K0 + 1) / 2) {
+            int k = 0, rem = tid;                                  // tid -> (k, j >= k) in the row-major upper triangle
+            while (rem >= K0 - k) { rem -= K0 - k; ++k; }
+            const int j = k + rem, i = K0 + tid;
+            const double v = ((part[0][i] + part[1][i]) + (part[2][i] + part[3][i])) / T0;
+            S[K0 + k * K0 + j] = v;
+            S[K0 + j * K0 + k] = v;
+        }
     }
     __syncthreads();
     for (int c = tid; c < C0; c += 256) {

@@ -110,6 +110,58 @@ __global__ __launch_bounds__(256) void posconv_gather_kernel(const float* __rest
 
 // logit[b] = mean_t(h[b,t,:]) . coef + intercept;  prob = sigmoid(logit)
 // (LMAC_metrics.py:130,146,156 pooling + classifier_embedder.py:34-38).  One workgroup per clip.
+// Fast path (H % 4 == 0, H <= 2048): wavefront w sums the frames t = w, w+4, ... with 16-byte loads (NV independent
+// accumulators per lane, two frames in flight), the four partial rows meet in LDS in a fixed order -> deterministic.
+template <int NV>
+__global__ __launch_bounds__(256) void pool_logreg_rows_kernel(const float* __restrict__ h, const float* __restrict__ coef,
+                                                               float intercept, float* __restrict__ logit,
+                                                               float* __restrict__ prob, float* __restrict__ pooled,
+                                                               int T, int H) {
+    extern __shared__ float part[];                       // [4][H]
+    __shared__ float red[4];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const float* hb = h + (long)b * T * H;
+    float4 acc[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int t = wv; t < T; t += 8) {
+        const bool two = t + 4 < T;
+        float4 a[NV], c2[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = 4 * (lane + 64 * i);
+            a[i] = c < H ? *(const float4*)(hb + (long)t * H + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            c2[i] = (two && c < H) ? *(const float4*)(hb + (long)(t + 4) * H + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            acc[i].x += a[i].x; acc[i].y += a[i].y; acc[i].z += a[i].z; acc[i].w += a[i].w;
+            acc[i].x += c2[i].x; acc[i].y += c2[i].y; acc[i].z += c2[i].z; acc[i].w += c2[i].w;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = 4 * (lane + 64 * i);
+        if (c < H) *(float4*)(part + wv * H + c) = acc[i];
+    }
+    __syncthreads();
+    float dot = 0.f;
+    for (int c = tid; c < H; c += 256) {
+        const float s = ((part[c] + part[H + c]) + (part[2 * H + c] + part[3 * H + c])) / T;
+        if (pooled) pooled[(long)b * H + c] = s;
+        dot += s * coef[c];
+    }
+    dot = wave_sum(dot);
+    if (lane == 0) red[wv] = dot;
+    __syncthreads();
+    if (tid == 0) {
+        float z = (red[0] + red[1]) + (red[2] + red[3]) + intercept;
+        logit[b] = z;
+        prob[b] = 1.f / (1.f + expf(-z));
+    }
+}
+
+// any H: one thread per channel, frames in order
 __global__ __launch_bounds__(256) void pool_logreg_kernel(const float* __restrict__ h, const float* __restrict__ coef,
                                                           float intercept, float* __restrict__ logit,
                                                           float* __restrict__ prob, float* __restrict__ pooled,
@@ -170,6 +222,13 @@ extern "C" int advh_posconv_gather(const float* h, void* xg, int B, int T, int H
 extern "C" int advh_pool_logreg(const float* h, const float* coef, float intercept, float* logit, float* prob,
                                 float* pooled, int B, int T, int H, advh_stream_t stream) {
     if (!h || !coef || !logit || !prob || B <= 0 || T <= 0 || H <= 0) return ADVH_EINVAL;
-    hipLaunchKernelGGL(pool_logreg_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, h, coef, intercept, logit, prob, pooled, T, H);
+    hipStream_t s = (hipStream_t)stream;
+    const size_t lds = 4 * (size_t)H * sizeof(float);
+    if (H % 4 == 0 && H <= 1024)
+        hipLaunchKernelGGL(pool_logreg_rows_kernel<4>, dim3(B), dim3(256), lds, s, h, coef, intercept, logit, prob, pooled, T, H);
+    else if (H % 4 == 0 && H <= 2048)
+        hipLaunchKernelGGL(pool_logreg_rows_kernel<8>, dim3(B), dim3(256), lds, s, h, coef, intercept, logit, prob, pooled, T, H);
+    else
+        hipLaunchKernelGGL(pool_logreg_kernel, dim3(B), dim3(256), 0, s, h, coef, intercept, logit, prob, pooled, T, H);
     return ADVH_LAUNCH_CHECK();
 }
