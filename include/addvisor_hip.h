@@ -210,6 +210,24 @@ int advh_layernorm(const void* in, int in_is_f32, int64_t in_ld, const float* ga
 int advh_posconv_gather(const float* h, void* xg, int B, int T, int H, int G, int K, int pad_left, const void* dact_src,
                         advh_stream_t stream);
 
+/* The grouped positional convolution itself as an LDS line-tile launch (csrc/posconv_tile.hip): one workgroup per
+ * (group, clip) stages the clip's gathered rows once and streams the group's weights through an LDS ring.
+ *   xg    [G][B][T+K][H/G] fp16 from advh_posconv_gather (pad_left = K/2)
+ *   W     fp16 [G][K*(H/G)/32 k-steps][H/G rows][32]: weight-norm-folded conv weight [n][tap][ci] of each group, cut
+ *         into 32-deep k-steps in (tap, ci) order
+ *   out[b][t][c] = resid[b][t][c] + GELU(conv + bias[c])   fp32 [B][T][H] (out may alias resid).
+ * Supported: K = 128, H/G in {48, 64}, T <= 256 (ADVH_EUNSUPPORTED otherwise: use the implicit GEMM).         */
+typedef struct advh_posconv_desc {
+    const void* xg;
+    const void* W;
+    const float* bias;
+    const float* resid;
+    float* out;
+    int B, T, H, G, K;
+} advh_posconv_desc;
+int advh_posconv_tile_f16(const advh_posconv_desc* d, advh_stream_t stream);
+int advh_posconv_tile_lds_bytes(int Cg, int T);   /* -1 = unsupported geometry */
+
 /* softmax(Q K^T / sqrt(d)) V without mask (modeling_wav2vec2.py:438-548), T <= 256, d in {32, 64}.
  * qkv [B*T][3H] fp16 (q | k | v), ctx [B*T][H] fp16. */
 int advh_attention_f16(const void* qkv, void* ctx, int B, int T, int H, int heads, advh_stream_t stream);

@@ -238,3 +238,38 @@ def test_fused_resblock_step(gpu_device, Cn, k, d, B, T):
     close(dst.interior().transpose(1, 2), ref, tol=3e-3)
     assert (dst.t[:, :32] == 0).all() and (dst.t[:, 32 + T:] == 0).all()
     assert not G.resblock_pair_supported(src, dst, rnd(g, 64, 64, 11), rnd(g, 64, 64, 11), 1) or Cn != 64    # 2 x 90 KB of weights
+
+
+@pytest.mark.parametrize("Cg,G_,B,T", [(48, 16, 3, 199), (64, 4, 2, 249), (48, 2, 5, 17), (64, 2, 1, 256)])
+def test_posconv_line_tile(gpu_device, Cg, G_, B, T):
+    """advh_posconv_tile_f16 (clip rows staged in LDS, weights streamed) against torch's grouped Conv1d on the same fp16
+    operands (modeling_wav2vec2.py:326-379: k = 128, padding 64, last frame dropped, GELU, residual add).
+    Stated tolerance 1e-4 on values of O(1) (same fp16 operands on both sides, fp32 accumulation over K = 128 * Cg;
+    measured 5e-6)."""
+    import ctypes
+    from addvisor_hip.embedder import PosconvDesc
+    K, H = 128, Cg * G_
+    g = torch.Generator().manual_seed(Cg + T)
+    h = torch.randn(B, T, H, generator=g)
+    w = torch.randn(H, Cg, K, generator=g) / (K * Cg) ** 0.5
+    bias = torch.randn(H, generator=g) * 0.1
+    lib = _lib.lib()
+    _lib.init()
+    assert lib.advh_posconv_tile_lds_bytes(Cg, T) > 0
+    hd = h.to(gpu_device).contiguous()
+    xg = torch.empty(G_, B, T + K, Cg, dtype=torch.float16, device=gpu_device)
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.advh_posconv_gather(hd.data_ptr(), xg.data_ptr(), B, T, H, G_, K, K // 2, None, st), "gather")
+    wt = w.view(G_, Cg, Cg, K).permute(0, 1, 3, 2).reshape(G_, Cg, K * Cg // 32, 32).permute(0, 2, 1, 3).contiguous().half().to(gpu_device)
+    bd = bias.to(gpu_device)
+    out = torch.empty_like(hd)
+    d = PosconvDesc()
+    d.xg, d.W, d.bias, d.resid, d.out = xg.data_ptr(), wt.data_ptr(), bd.data_ptr(), hd.data_ptr(), out.data_ptr()
+    d.B, d.T, d.H, d.G, d.K = B, T, H, G_, K
+    _lib.check(lib.advh_posconv_tile_f16(ctypes.byref(d), st), "advh_posconv_tile_f16")
+    conv = F.conv1d(h.half().float().transpose(1, 2), w.half().float(), bias, padding=K // 2, groups=G_)[:, :, :T]
+    ref = h + F.gelu(conv).transpose(1, 2)
+    err = (out.cpu() - ref).abs().max().item()
+    print(f"posconv line tile Cg={Cg} T={T}: max err {err:.2e}")
+    assert err <= 1e-4
+    assert lib.advh_posconv_tile_lds_bytes(40, T) == -1 and lib.advh_posconv_tile_lds_bytes(Cg, 300) == -1

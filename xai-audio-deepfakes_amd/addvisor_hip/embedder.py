@@ -11,6 +11,8 @@ residual stream / LayerNorm / softmax statistics are fp32.
 """
 from __future__ import annotations
 
+import ctypes
+import os
 from typing import Dict, List, Optional, Tuple
 
 import numpy as np
@@ -18,6 +20,15 @@ import torch
 
 from . import _lib, gemm as G
 from .synthetic import EmbedderConfig
+
+POSCONV_TILE = os.environ.get("ADDVISOR_POSCONV_TILE", "1") != "0"     # A/B switch: 0 = implicit GEMM for the positional conv
+
+
+class PosconvDesc(ctypes.Structure):
+    """advh_posconv_desc (include/addvisor_hip.h)."""
+    _fields_ = [("xg", ctypes.c_void_p), ("W", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("resid", ctypes.c_void_p),
+                ("out", ctypes.c_void_p), ("B", ctypes.c_int), ("T", ctypes.c_int), ("H", ctypes.c_int),
+                ("G", ctypes.c_int), ("K", ctypes.c_int)]
 
 
 def _f32(t, dev):
@@ -140,6 +151,17 @@ class HipEmbedder:
                                window=(0, 1, 0, T), halo_zero=False, out=(T * H, 0, H, 0), n_div=G.round_up(Cg, 4),
                                o_sZ=Cg, nz=Gp, bias=sd["encoder.pos_conv_embed.conv.bias"], bias_sZ=Cg, act="gelu",
                                device=dev, cache=(self._wcache, "pos"))
+        # line-tile launch for the same layer (csrc/posconv_tile.hip): the clip's gathered rows staged in LDS once, the
+        # group's weights streamed; the implicit GEMM above stays as the fallback for other geometries
+        ws["pos_tile"] = None
+        if POSCONV_TILE and _lib.lib().advh_posconv_tile_lds_bytes(Cg, T) > 0 and K == 128:
+            if "pos_tile" not in self._wcache:
+                wt = w2().view(Gp, Cg, K * Cg // 32, 32).permute(0, 2, 1, 3).contiguous().to(torch.float16)   # [g][k-step][n][32]
+                self._wcache["pos_tile"] = (wt.to(dev), sd["encoder.pos_conv_embed.conv.bias"].float().contiguous().to(dev))
+            d = PosconvDesc()
+            d.B, d.T, d.H, d.G, d.K = B, T, H, Gp, K
+            d.W, d.bias = self._wcache["pos_tile"][0].data_ptr(), self._wcache["pos_tile"][1].data_ptr()
+            ws["pos_tile"] = d
         layers = []
         for l in range(self.nl):
             p = f"encoder.layers.{l}."
@@ -208,7 +230,12 @@ class HipEmbedder:
         ws["proj"].run(ws["featn"], out_f=h)
         K, Gp = cfg.num_conv_pos_embeddings, cfg.num_conv_pos_embedding_groups
         _lib.check(lib.advh_posconv_gather(h.data_ptr(), ws["xg"].data_ptr(), B, T, H, Gp, K, K // 2, None, st), "advh_posconv_gather")
-        ws["pos"].run(ws["xg"], out_f=h, resid=h)                     # h += gelu(pos_conv(h))
+        if ws["pos_tile"] is not None:                                # h += gelu(pos_conv(h))
+            d = ws["pos_tile"]
+            d.xg, d.resid, d.out = ws["xg"].data_ptr(), h.data_ptr(), h.data_ptr()
+            _lib.check(lib.advh_posconv_tile_f16(ctypes.byref(d), st), "advh_posconv_tile_f16")
+        else:
+            ws["pos"].run(ws["xg"], out_f=h, resid=h)
         stable = cfg.do_stable_layer_norm
         if not stable:
             self.enc_ln(h, M, eps, out_f=h, out_h=h16)
