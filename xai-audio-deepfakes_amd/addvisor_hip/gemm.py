@@ -523,7 +523,7 @@ def plan_upconv2d(coarse: FMap, skip: FMap, dst: FMap, wt: torch.Tensor, bt: tor
                  Source(skip.Hp * skip.Wp * cc1, sh * skip.Wp * cc1, sw * cc1, c0_1, sZ=skip.Wp * cc1, sZ2=cc1 if sw == 2 else 0)],
         Hg=coarse.H, Wg=coarse.W, window=(0, coarse.H, 0, coarse.W), halo_zero=False,
         out=(dst.Hp * dst.Wp * Ct, sh * dst.Wp * Ct, sw * Ct, o_c0), o_sZ=dst.Wp * Ct, o_sZ2=Ct if sw == 2 else 0,
-        nz=sh * sw, nz_lo=sw, z_inner=True, bias=bc, bias_sZ=0, act="leaky", slope=slope, device=device)
+        nz=sh * sw, nz_lo=sw, z_inner=os.environ.get("ADDVISOR_UPCONV_Z_INNER", "1") != "0", bias=bc, bias_sZ=0, act="leaky", slope=slope, device=device)
     plans = [plan]
     flops = 2.0 * dst.B * dst.H * dst.W * N * (nth * ntw * Cb + 9 * Cs + (nth * ntw if where == "coarse" else 9))
     return PlanGroup(plans, flops)
