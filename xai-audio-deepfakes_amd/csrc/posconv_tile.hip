@@ -25,13 +25,67 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int PC_K = 128, PC_RING = 3, PC_BLK = 4;               // taps; ring slots; k-steps per weight block
 
+#define DS_READ128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#define LGKM_WAIT(n) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(n) : "memory")
+
+// One weight block (PC_BLK k-steps) for a wavefront that owns NJ frame tiles: the operands of k-step ks+1 are read from
+// LDS between the MFMAs of k-step ks (register double buffer), so only the first reads of a block are exposed.
+template <int CC, int NJ>
+__device__ __forceinline__ void posconv_block(f32x4 (&acc)[4][CC / 2], unsigned wb, const unsigned (&xrow)[4], int& cc, unsigned& xoff) {
+    constexpr int CG = CC * 8, NI = CG / 16, PITCH = (CC + 1) * 16, NR = NI + NJ;
+    if constexpr (NJ > 0) {
+        f16x8 wf[2][NI], xf[2][NJ];
+        unsigned xo[2];
+        xo[0] = xoff;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) DS_READ128(wf[0][i], wb, i * 16 * 64);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) { const unsigned a = xrow[j] + xo[0]; DS_READ128(xf[0][j], a, 0); }
+#pragma unroll
+        for (int ks = 0; ks < PC_BLK; ++ks) {
+            const int cur = ks & 1, nxt = cur ^ 1;
+            cc += 4;
+            xoff += 64;
+            if (cc >= CC) { cc -= CC; xoff += PITCH - CC * 16; }
+            xo[nxt] = xoff;
+            const unsigned wn = wb + (unsigned)((ks + 1) * CG * 64);
+            LGKM_WAIT(0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < NJ * NI; ++m) {
+                const int j = m / NI, i = m % NI;
+                acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[cur][i], xf[cur][j], acc[j][i], 0, 0, 0);
+                if (ks + 1 < PC_BLK && m < NR) {
+                    if (m < NI) DS_READ128(wf[nxt][m < NI ? m : 0], wn, (m < NI ? m : 0) * 16 * 64);
+                    else { const unsigned a = xrow[m - NI < NJ ? m - NI : 0] + xo[nxt]; DS_READ128(xf[nxt][m - NI < NJ ? m - NI : 0], a, 0); }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (ks + 1 < PC_BLK) {                                // fewer MFMAs than operand reads (NJ = 1): issue the rest
+#pragma unroll
+                for (int m = NJ * NI; m < NR; ++m) {
+                    if (m < NI) DS_READ128(wf[nxt][m < NI ? m : 0], wn, (m < NI ? m : 0) * 16 * 64);
+                    else { const unsigned a = xrow[m - NI < NJ ? m - NI : 0] + xo[nxt]; DS_READ128(xf[nxt][m - NI < NJ ? m - NI : 0], a, 0); }
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int ks = 0; ks < PC_BLK; ++ks) {
+            cc += 4;
+            xoff += 64;
+            if (cc >= CC) { cc -= CC; xoff += PITCH - CC * 16; }
+        }
+    }
+}
+
 template <int CC>                                                // 16-byte chunks per row = channels per group / 8 (6 or 8)
 __global__ __launch_bounds__(256, 2) void posconv_tile_kernel(const advh_posconv_desc p) {
     constexpr int CG = CC * 8, NI = CG / 16, SLOTS = CC + 1, PITCH = SLOTS * 16;   // odd slot count: conflict-free row reads
     constexpr int KSTEPS = PC_K * CC / 4, NBLK = KSTEPS / PC_BLK, WBLK = PC_BLK * CG * 64, WL = WBLK / 16 / 256, MT = 4;
     static_assert(WBLK % (256 * 16) == 0 && KSTEPS % PC_BLK == 0, "weight block = whole loads per thread");
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, g = lane >> 4;
     const int rows = p.T + PC_K - 1, nt = (p.T + 15) / 16;
     const int nX = (rows * SLOTS + 63) & ~63;                    // chunks of the staged clip (whole-wave loads)
@@ -69,39 +123,26 @@ __global__ __launch_bounds__(256, 2) void posconv_tile_kernel(const advh_posconv
 #pragma unroll
             for (int i = 0; i < NI; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
         // this lane group's chunk of k-step s is 4 s + g -> (tap, chunk-in-row); kept as a byte offset into the staged clip
-        int cc = g % CC, tap = g / CC;
-        unsigned xoff = (unsigned)(tap * PITCH + cc * 16);
-        const char* xrow[MT];
+        int cc = g;                                              // g < 4 <= CC: tap 0
+        unsigned xoff = (unsigned)(g * 16);
+        const unsigned lds0 = (unsigned)(unsigned long)LDS_PTR(lds);
+        unsigned xrow[MT];
 #pragma unroll
-        for (int j = 0; j < MT; ++j) xrow[j] = Xl + (16 * min(wv + 4 * j, nt - 1) + fr) * PITCH;
-        const int nj = (nt - wv + 3) / 4;                         // frame tiles wv, wv+4, ... < nt of this wavefront (wave-uniform)
-        const unsigned wlane = (unsigned)((fr * 4 + (g ^ ((fr >> 1) & 2))) * 16);
+        for (int j = 0; j < MT; ++j) xrow[j] = lds0 + PC_RING * WBLK + (unsigned)((16 * min(wv + 4 * j, nt - 1) + fr) * PITCH);
+        const int nj = max(0, min(MT, (nt - wv + 3) / 4));        // frame tiles wv, wv+4, ... < nt of this wavefront (wave-uniform)
+        const unsigned wlane = lds0 + (unsigned)((fr * 4 + (g ^ ((fr >> 1) & 2))) * 16);
         for (int blk = 0; blk < NBLK; ++blk) {
             if (blk + 1 < NBLK) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WL) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();                                     // block blk landed for everyone; slot (blk+2) % 3 is free
             if (blk + 2 < NBLK) issue_w(blk + 2);
-            const char* wb = lds + (blk % PC_RING) * WBLK + wlane;
-#pragma unroll
-            for (int ks = 0; ks < PC_BLK; ++ks) {
-                f16x8 wf[NI], xf[MT];
-#pragma unroll
-                for (int i = 0; i < NI; ++i)
-                    wf[i] = *(const f16x8*)(wb + (ks * CG + i * 16) * 64);
-#pragma unroll
-                for (int j = 0; j < MT; ++j)
-                    xf[j] = *(const f16x8*)(xrow[j] + xoff);
-#pragma unroll
-                for (int j = 0; j < MT; ++j) {
-                    if (j < nj) {
-#pragma unroll
-                        for (int i = 0; i < NI; ++i)
-                            acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xf[j], acc[j][i], 0, 0, 0);
-                    }
-                }
-                cc += 4;
-                xoff += 64;
-                if (cc >= CC) { cc -= CC; xoff += PITCH - CC * 16; }
+            const unsigned wb = wlane + (unsigned)(blk % PC_RING) * WBLK;
+            switch (nj) {
+                case 4: posconv_block<CC, 4>(acc, wb, xrow, cc, xoff); break;
+                case 3: posconv_block<CC, 3>(acc, wb, xrow, cc, xoff); break;
+                case 2: posconv_block<CC, 2>(acc, wb, xrow, cc, xoff); break;
+                case 1: posconv_block<CC, 1>(acc, wb, xrow, cc, xoff); break;
+                default: posconv_block<CC, 0>(acc, wb, xrow, cc, xoff); break;
             }
         }
         // h[b][t][grp*CG + 16 i + 4 g + r] += GELU(acc + bias)
