@@ -119,6 +119,7 @@ enum { ADVH_TILE_AUTO = 0, ADVH_TILE_128x128 = 1, ADVH_TILE_256x64 = 2, ADVH_TIL
        ADVH_TILE_256x256_RING = 8 /* 512-thread, 32-deep K-tiles in a 4-stage LDS ring */,
        ADVH_TILE_256x128_W8 = 9, ADVH_TILE_128x256_W8 = 10 /* 512-thread single-buffer kernel, 64x64 wave tiles, 2 workgroups per CU */,
        ADVH_TILE_256x256_W4 = 12 /* 256-thread 2-stage ring, 128x128 wave tiles, one wavefront per SIMD */,
+       ADVH_TILE_128x128_O5 = 13 /* the 128x128 tile compiled for five workgroups per CU (<= 96 VGPRs) */,
        ADVH_TILE_256x128_PERSIST = 11 /* persistent 3-stage ring: one workgroup per CU walks tiles, K-steps of consecutive tiles form one DMA stream */ };
 
 typedef struct advh_gemm_desc {
@@ -177,6 +178,15 @@ typedef struct advh_gemm_desc {
     int32_t nz_lo, z_inner;
     int64_t a_sZ2[2];
     int64_t o_sZ2;
+    /* plain = 1 (requires ktab_identity and one source): every row m in [0, M) -- valid or not -- may be read at chunk
+       a_c0[0] + m * a_sW[0] (+ z * a_sZ[0]), K contiguous chunks; a_sB / a_sH / the window are then used for the OUTPUT
+       addressing only.  Lets the 128x128 tile run its affine-row loader (Linear layers, feature-encoder Conv1d: the
+       caller guarantees that the last row's K chunks are inside the allocation).                                  */
+    int32_t plain;
+    /* plain_out = 1 (with plain): every row is valid (the window is the whole grid), output row m starts at
+       o_c0 + m * o_sW + the batch offset and the columns are one block (n_div >= N, no phases, no sub-pixel split):
+       the epilogue skips the row decomposition and the column divisions.                                          */
+    int32_t plain_out;
 } advh_gemm_desc;
 
 int advh_gemm_f16(const advh_gemm_desc* desc, int tile, advh_stream_t stream);

@@ -21,6 +21,7 @@ import torch
 from . import _lib, gemm as G
 from .synthetic import EmbedderConfig
 
+FE_SLACK_ROWS = 4
 POSCONV_TILE = os.environ.get("ADDVISOR_POSCONV_TILE", "1") != "0"     # A/B switch: 0 = implicit GEMM for the positional conv
 
 
@@ -115,8 +116,9 @@ class HipEmbedder:
         ws["stats"] = torch.empty(B, 2, dtype=f32, device=dev)
         ws["norm"] = torch.empty(B, C[0], 2, dtype=f32, device=dev)
         ws["mr"] = torch.empty(B, C[0], 2, dtype=f32, device=dev)
-        ws["fe"] = [torch.empty(B * P[0] * C[0], dtype=h16, device=dev),
-                    torch.empty(B * P[1] * C[1], dtype=h16, device=dev)]
+        # + FE_SLACK_ROWS readable rows behind each buffer: the last filler row of a layer reaches k - stride rows past it
+        ws["fe"] = [torch.zeros(B * P[0] * C[0] + FE_SLACK_ROWS * max(C), dtype=h16, device=dev),
+                    torch.zeros(B * P[1] * C[1] + FE_SLACK_ROWS * max(C), dtype=h16, device=dev)]
         ws["feat"] = torch.empty(M, C[-1], dtype=h16, device=dev)
         ws["featn"] = torch.empty(M, C[-1], dtype=h16, device=dev)
         ws["h"] = torch.empty(M, H, dtype=f32, device=dev)
@@ -136,7 +138,7 @@ class HipEmbedder:
             p = f"feature_extractor.conv_layers.{i}.conv."
             fe_plans.append(G.plan_conv1d_cl(B, P[i - 1], P[i], Ls[i], sd[p + "weight"], sd.get(p + "bias"),
                                              strides[i], act=act, compact_out=(i == nfe - 1), device=dev,
-                                             cache=(self._wcache, ("fe", i))))
+                                             cache=(self._wcache, ("fe", i)), slack_rows=FE_SLACK_ROWS))
         ws["fe_plans"] = fe_plans
         ws["proj"] = G.plan_linear(M, sd["feature_projection.projection.weight"],
                                    sd["feature_projection.projection.bias"], device=dev, cache=(self._wcache, "proj"))

@@ -27,16 +27,17 @@ def packed_row_channel(rows: int) -> np.ndarray:
     R = np.arange(rows)
     return ((R >> 5) << 5) + (((R >> 2) & 3) << 3) + (((R >> 4) & 1) << 2) + (R & 3)
 TILE_AUTO, TILE_128x128, TILE_256x64, TILE_256x32, TILE_256x256, TILE_256x128, TILE_256x128_W4, TILE_128x256_W4, TILE_256x256_RING = 0, 1, 2, 3, 4, 5, 6, 7, 8
-TILE_256x128_W8, TILE_128x256_W8, TILE_256x128_PERSIST, TILE_256x256_W4 = 9, 10, 11, 12
+TILE_256x128_W8, TILE_128x256_W8, TILE_256x128_PERSIST, TILE_256x256_W4, TILE_128x128_O5 = 9, 10, 11, 12, 13
 TILE_BN = {TILE_128x128: 128, TILE_256x64: 64, TILE_256x32: 32, TILE_256x256: 256, TILE_256x128: 128, TILE_256x128_W4: 128, TILE_128x256_W4: 256, TILE_256x256_RING: 256,
-           TILE_256x128_W8: 128, TILE_128x256_W8: 256, TILE_256x128_PERSIST: 128, TILE_256x256_W4: 256}
+           TILE_256x128_W8: 128, TILE_128x256_W8: 256, TILE_256x128_PERSIST: 128, TILE_256x256_W4: 256, TILE_128x128_O5: 128}
 TILE_NAMES = {TILE_128x128: "128x128", TILE_256x64: "256x64", TILE_256x32: "256x32", TILE_256x256: "256x256p", TILE_256x128: "256x128p",
               TILE_256x128_W4: "256x128w4", TILE_128x256_W4: "128x256w4", TILE_256x256_RING: "256x256r",
-              TILE_256x128_W8: "256x128w8", TILE_128x256_W8: "128x256w8", TILE_256x128_PERSIST: "256x128ps", TILE_256x256_W4: "256x256w4"}
+              TILE_256x128_W8: "256x128w8", TILE_128x256_W8: "128x256w8", TILE_256x128_PERSIST: "256x128ps", TILE_256x256_W4: "256x256w4", TILE_128x128_O5: "128x128o5"}
 # device symbol (as rocprofv3 prints it) of the kernels the live profile covers
 TILE_KERNELS = {TILE_128x128: "gemm_f16_kernel<128, 128, 2, 2, 3>", TILE_128x256_W8: "gemm_f16_kernel<128, 256, 2, 4, 3>",
                 TILE_256x128_W8: "gemm_f16_kernel<256, 128, 4, 2, 3>", TILE_256x256: "gemm_f16_pipe_kernel<256, 256, 2, 4, 2>",
-                TILE_256x128: "gemm_f16_pipe_kernel<256, 128, 4, 2, 3>", TILE_256x128_PERSIST: "gemm_f16_persist_kernel<256, 128, 4, 2>"}
+                TILE_256x128: "gemm_f16_pipe_kernel<256, 128, 4, 2, 3>", TILE_256x128_PERSIST: "gemm_f16_persist_kernel<256, 128, 4, 2>",
+                TILE_128x128_O5: "gemm_f16_kernel<128, 128, 2, 2, 5>"}
 
 
 class GemmDesc(C.Structure):
@@ -55,7 +56,7 @@ class GemmDesc(C.Structure):
         ("resid_f32", C.c_int32), ("ktab_identity", C.c_int32),
         ("out_h2", C.c_void_p), ("slope2", C.c_float), ("ph_r", C.c_int32), ("ph_pad", C.c_int32), ("ph_T", C.c_int32),
         ("out_pre", C.c_void_p), ("dact_src", C.c_void_p), ("wide", C.c_int32), ("w_ld", C.c_int64), ("sc", C.c_int32), ("n_sub", C.c_int32), ("o_sNhh", C.c_int64),
-        ("nz_lo", C.c_int32), ("z_inner", C.c_int32), ("a_sZ2", C.c_int64 * 2), ("o_sZ2", C.c_int64),
+        ("nz_lo", C.c_int32), ("z_inner", C.c_int32), ("a_sZ2", C.c_int64 * 2), ("o_sZ2", C.c_int64), ("plain", C.c_int32), ("plain_out", C.c_int32),
     ]
 
 
@@ -125,6 +126,10 @@ def super_columns(N: int, Kp: int, M: int) -> int:
     return sc if sc >= 4 else 0            # narrower super-columns re-read the activations too often (deep-K layers)
 
 
+PLAIN_ROWS = os.environ.get("ADDVISOR_GEMM_PLAIN", "1") != "0"          # A/B switch for the affine-row loader
+TILE128 = int(os.environ.get("ADDVISOR_GEMM_TILE128", str(TILE_128x128)))     # experiment switch: 13 = the five-workgroup build
+
+
 def pick_tile(N: int, M: int = 0) -> Tuple[int, int]:
     """(tile id, BN) the AUTO rule of advh_gemm_f16 picks (same rule as csrc/gemm.hip).  The 512-thread 128x256 /
     256x128 tiles win an isolated-GEMM loop by 10-15 % on the 3B-row shapes but lose ~3 % inside the pipeline
@@ -133,7 +138,7 @@ def pick_tile(N: int, M: int = 0) -> Tuple[int, int]:
         return TILE_256x32, 32
     if N <= 64:
         return TILE_256x64, 64
-    return TILE_128x128, 128
+    return TILE128, 128
 
 
 @dataclass
@@ -156,7 +161,7 @@ class GemmPlan:
                  o_sZ: int = 0, nz: int = 1, bias: Optional[torch.Tensor] = None, act: str = "none",
                  slope: float = 0.0, device=None, w_sZ: Optional[int] = None, bias_sZ: int = 0,
                  slope2: float = 0.0, phase: Tuple[int, int, int] = (0, 0, 0), cache: Optional[tuple] = None,
-                 n_sub: int = 0, o_sNhh: int = 0, nz_lo: int = 0, z_inner: bool = False, o_sZ2: int = 0):
+                 n_sub: int = 0, o_sNhh: int = 0, nz_lo: int = 0, z_inner: bool = False, o_sZ2: int = 0, plain: bool = False):
         """``w2``: fp32 ``[nz, N, K]`` (K = 8 * len(ktab) before padding) or a zero-argument callable returning it
         (only called when the packed weight is not in ``cache``); ``ktab``: int64 chunk offsets with bit 31 as
         source selector; ``out`` = (o_sB, o_sH, o_sW, o_c0) in elements.  ``cache = (dict, key)`` shares the
@@ -223,6 +228,15 @@ class GemmPlan:
         d.slope2 = slope2
         d.ph_r, d.ph_pad, d.ph_T = phase
         d.ktab_identity = int(bool((kt == np.arange(len(kt))).all()))
+        # affine-row loader of the 128x128 tile: row m at a_c0 + m * a_sW, also for rows the window excludes
+        d.plain = int(bool(plain and PLAIN_ROWS and d.ktab_identity and len(sources) == 1))
+        if d.plain:
+            src = sources[0]
+            assert Hg == 1 or src.sH == Wg * src.sW, "plain rows need h * a_sH == (h * Wg) * a_sW"
+            assert M <= Hg * Wg or src.sB == Hg * Wg * src.sW, "plain rows need b * a_sB == (b * Hg * Wg) * a_sW"
+        o_sB, o_sH, o_sW, _ = out
+        d.plain_out = int(bool(d.plain and n_div_v >= N and phase[0] == 0 and n_sub <= 1 and tuple(window) == (0, Hg, 0, Wg)
+                               and (Hg == 1 or o_sH == Wg * o_sW) and (M <= Hg * Wg or o_sB == Hg * Wg * o_sW)))
         d.sc = super_columns(N, Kp, M)
         self.desc = d
         self.nsrc = len(sources)
@@ -349,14 +363,17 @@ def plan_linear(M: int, weight: torch.Tensor, bias: Optional[torch.Tensor], *, l
     assert lda % 8 == 0 and ldo % 4 == 0
     return GemmPlan(M=M, N=N, w2=lambda: weight[None].float(), ktab=np.arange(K // 8, dtype=np.int64),
                     sources=[Source(0, 0, lda // 8, 0)], Hg=1, Wg=M, window=(0, 1, 0, M), halo_zero=False,
-                    out=(0, 0, ldo, o_c0), bias=bias, act=act, device=device, cache=cache)
+                    out=(0, 0, ldo, o_c0), bias=bias, act=act, device=device, cache=cache, plain=True)
 
 
 def plan_conv1d_cl(B: int, P_in: int, P_out: int, L_out: int, weight: torch.Tensor, bias: Optional[torch.Tensor],
-                   stride: int, *, act: str = "gelu", compact_out: bool = False, device=None, cache=None) -> GemmPlan:
+                   stride: int, *, act: str = "gelu", compact_out: bool = False, device=None, cache=None,
+                   slack_rows: int = 0) -> GemmPlan:
     """Channels-last Conv1d (no padding) as an overlapping-row GEMM: wav2vec2 feature-encoder layers 1-6
     (modeling_wav2vec2.py:254-323).  Input ``[B, P_in, Cin]``, rows >= L_in are zero filler; output
-    ``[B, P_out, Cout]`` with rows >= L_out written as zeros, or ``[B, L_out, Cout]`` if ``compact_out``."""
+    ``[B, P_out, Cout]`` with rows >= L_out written as zeros, or ``[B, L_out, Cout]`` if ``compact_out``.
+    ``slack_rows``: readable rows the caller allocated behind the input; with ``>= k - stride`` (the reach of the last
+    filler row) and ``P_in == P_out * stride`` the launch uses the affine-row loader (``desc.plain``)."""
     Cout, Cin, k = weight.shape
     assert Cin % 8 == 0
     w2 = lambda: weight.permute(0, 2, 1).reshape(1, Cout, k * Cin).float()  # K order: (tap, channel)
@@ -364,7 +381,7 @@ def plan_conv1d_cl(B: int, P_in: int, P_out: int, L_out: int, weight: torch.Tens
     return GemmPlan(M=B * P_out, N=Cout, w2=w2, ktab=np.arange(k * Cin // 8, dtype=np.int64),
                     sources=[Source(P_in * Cin // 8, 0, stride * Cin // 8, 0)], Hg=1, Wg=P_out,
                     window=(0, 1, 0, L_out), halo_zero=not compact_out, out=out, bias=bias, act=act, device=device,
-                    cache=cache)
+                    cache=cache, plain=(slack_rows >= k - stride and P_in == P_out * stride))
 
 
 def plan_conv2d(srcs: Sequence[FMap], dst: FMap, weight: torch.Tensor, bias: Optional[torch.Tensor], *,
