@@ -20,7 +20,7 @@ import numpy as np
 import torch
 
 from . import _lib, gemm as G
-from .embedder import HipEmbedder
+from .embedder import FE_SLACK_ROWS, HipEmbedder
 
 
 def plan_conv1d_dgrad(B: int, P_out: int, weight: torch.Tensor, stride: int, device=None, cache=None) -> G.GemmPlan:
@@ -73,7 +73,9 @@ class EmbedderGrad:
         z = lambda *s, dt=h16: torch.zeros(*s, dtype=dt, device=dev)
         w = dict(f=f)
         # forward saves ------------------------------------------------------------------
-        w["y"] = [z(B * P[i] * C[i]) for i in range(nfe - 1)]                    # post-GELU outputs of layers 0..5
+        # post-GELU outputs of layers 0..5, each followed by the readable slack rows the affine-row loader of the next
+        # layer's plan may touch (gemm.plan_conv1d_cl(slack_rows=...))
+        w["y"] = [z((B * P[i] + FE_SLACK_ROWS) * C[i]) for i in range(nfe - 1)]
         w["z"] = [z(B * P[0] * C[0]) if self.layer_mode else None]             # pre-norm / pre-GELU outputs of the convs
         w["z"] += [z(B * P[i] * C[i]) for i in range(1, nfe - 1)] + [z(M, C[-1])]
         w["dyb"] = z(B * P[0] * C[0]) if self.layer_mode else None

@@ -71,41 +71,47 @@ struct RowDecomp {
 // Wide form (p.wide == 1): the host packed the weight rows permuted inside every 32-row block (R -> channel
 // 32 (R>>5) + 8 ((R>>2)&3) + 4 ((R>>4)&1) + (R&3)), so the tile pair (2q, 2q+1) of a lane is 8 CONSECUTIVE channels:
 // 16-byte fp16 / 32-byte fp32 accesses, 64 / 128 contiguous bytes per row and instruction.
+// value path of one VW-wide group: bias, pre-activation copy, activation, activation-derivative factor
 template <int VW>
-__device__ __forceinline__ void epilogue_store(const advh_gemm_desc& p, float (&v)[VW], bool ok, const float* bias, int n, long o) {
+__device__ __forceinline__ void epilogue_value(const advh_gemm_desc& p, float (&v)[VW], const float* bias, int n, long o) {
     typedef _Float16 hvec __attribute__((ext_vector_type(VW)));
-    if (ok) {
-        if (bias) {
+    if (bias) {
 #pragma unroll
-            for (int c = 0; c < VW; c += 4) { float4 bb = *(const float4*)(bias + n + c); v[c] += bb.x; v[c + 1] += bb.y; v[c + 2] += bb.z; v[c + 3] += bb.w; }
-        }
-        if (p.out_pre) {
-            hvec pv;
-#pragma unroll
-            for (int r = 0; r < VW; ++r) pv[r] = (_Float16)v[r];
-            *(hvec*)((_Float16*)p.out_pre + o) = pv;
-        }
-#pragma unroll
-        for (int r = 0; r < VW; ++r) v[r] = apply_act(v[r], p.act, p.slope);
-        if (p.dact_src) {
-            hvec zz = *(const hvec*)((const _Float16*)p.dact_src + o);
-#pragma unroll
-            for (int r = 0; r < VW; ++r) v[r] *= gelu_grad((float)zz[r]);
-        }
-        if (p.resid) {
-            if (p.resid_f32) {
-#pragma unroll
-                for (int c = 0; c < VW; c += 4) { float4 rr = *(const float4*)((const float*)p.resid + o + c); v[c] += rr.x; v[c + 1] += rr.y; v[c + 2] += rr.z; v[c + 3] += rr.w; }
-            } else {
-                hvec rr = *(const hvec*)((const _Float16*)p.resid + o);
-#pragma unroll
-                for (int r = 0; r < VW; ++r) v[r] += (float)rr[r];
-            }
-        }
-    } else {
-#pragma unroll
-        for (int r = 0; r < VW; ++r) v[r] = 0.f;
+        for (int c = 0; c < VW; c += 4) { float4 bb = *(const float4*)(bias + n + c); v[c] += bb.x; v[c + 1] += bb.y; v[c + 2] += bb.z; v[c + 3] += bb.w; }
     }
+    if (p.out_pre) {
+        hvec pv;
+#pragma unroll
+        for (int r = 0; r < VW; ++r) pv[r] = (_Float16)v[r];
+        *(hvec*)((_Float16*)p.out_pre + o) = pv;
+    }
+#pragma unroll
+    for (int r = 0; r < VW; ++r) v[r] = apply_act(v[r], p.act, p.slope);
+    if (p.dact_src) {
+        hvec zz = *(const hvec*)((const _Float16*)p.dact_src + o);
+#pragma unroll
+        for (int r = 0; r < VW; ++r) v[r] *= gelu_grad((float)zz[r]);
+    }
+}
+
+template <int VW>
+__device__ __forceinline__ void epilogue_resid(const advh_gemm_desc& p, float (&v)[VW], long o) {
+    typedef _Float16 hvec __attribute__((ext_vector_type(VW)));
+    if (p.resid) {
+        if (p.resid_f32) {
+#pragma unroll
+            for (int c = 0; c < VW; c += 4) { float4 rr = *(const float4*)((const float*)p.resid + o + c); v[c] += rr.x; v[c + 1] += rr.y; v[c + 2] += rr.z; v[c + 3] += rr.w; }
+        } else {
+            hvec rr = *(const hvec*)((const _Float16*)p.resid + o);
+#pragma unroll
+            for (int r = 0; r < VW; ++r) v[r] += (float)rr[r];
+        }
+    }
+}
+
+template <int VW>
+__device__ __forceinline__ void epilogue_write(const advh_gemm_desc& p, float (&v)[VW], long o) {
+    typedef _Float16 hvec __attribute__((ext_vector_type(VW)));
     if (p.out_f) {
 #pragma unroll
         for (int c = 0; c < VW; c += 4) *(float4*)((float*)p.out_f + o + c) = make_float4(v[c], v[c + 1], v[c + 2], v[c + 3]);
@@ -124,18 +130,52 @@ __device__ __forceinline__ void epilogue_store(const advh_gemm_desc& p, float (&
     }
 }
 
+template <int VW>
+__device__ __forceinline__ void epilogue_store(const advh_gemm_desc& p, float (&v)[VW], bool ok, const float* bias, int n, long o) {
+    if (ok) {
+        epilogue_value<VW>(p, v, bias, n, o);
+        epilogue_resid<VW>(p, v, o);
+    } else {
+#pragma unroll
+        for (int r = 0; r < VW; ++r) v[r] = 0.f;
+    }
+    epilogue_write<VW>(p, v, o);
+}
+
 // Lean form for desc.plain_out (every row valid, output row m at o_c0 + m * o_sW, one column block): no row
 // decomposition, no runtime divisions -- the epilogue of the Linear layers, where K = 768 makes it 10-30 % of a tile.
 template <int MI, int NI>
 __device__ __forceinline__ void gemm_epilogue_lean(const advh_gemm_desc& p, f32x4 (&acc)[NI][MI], int mw0, int nw0, int fr, int fq, int z,
                                                    long zo) {
     const float* bias = p.bias ? p.bias + (long)p.bias_sZ * z : nullptr;
+    if (p.wide) {
+        // The residual of a row (all its column pairs) is loaded before anything of that row is stored: with
+        // out == resid (h += ...) the compiler must keep every load behind the previous store, which made the epilogue a
+        // chain of eight exposed memory latencies per lane; now it is four (two rows at a time would cost a workgroup
+        // per CU: 156 VGPRs).
+        const bool pre = p.resid != nullptr;
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-        const int m = mw0 + mi * 16 + fr;
-        if (m >= p.M) continue;
-        const long orow = (long)m * p.o_sW + p.o_c0 + zo;
-        if (p.wide) {
+        for (int mi = 0; mi < MI; ++mi) {
+            const int m = mw0 + mi * 16 + fr;
+            if (m >= p.M) continue;
+            const long orow = (long)m * p.o_sW + p.o_c0 + zo;
+            float rv[NI / 2][8];
+            if (pre) {
+#pragma unroll
+                for (int q = 0; q < NI / 2; ++q) {
+                    const int n = nw0 + q * 32 + fq * 8;
+                    const long o = orow + (n < p.N ? n : 0);
+                    if (p.resid_f32) {
+                        const float4 r0 = *(const float4*)((const float*)p.resid + o), r1 = *(const float4*)((const float*)p.resid + o + 4);
+                        rv[q][0] = r0.x; rv[q][1] = r0.y; rv[q][2] = r0.z; rv[q][3] = r0.w;
+                        rv[q][4] = r1.x; rv[q][5] = r1.y; rv[q][6] = r1.z; rv[q][7] = r1.w;
+                    } else {
+                        const f16x8 rr = *(const f16x8*)((const _Float16*)p.resid + o);
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) rv[q][r] = (float)rr[r];
+                    }
+                }
+            }
 #pragma unroll
             for (int q = 0; q < NI / 2; ++q) {
                 const int n = nw0 + q * 32 + fq * 8;
@@ -143,16 +183,27 @@ __device__ __forceinline__ void gemm_epilogue_lean(const advh_gemm_desc& p, f32x
                 float v[8];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { v[r] = acc[2 * q][mi][r]; v[4 + r] = acc[2 * q + 1][mi][r]; }
-                epilogue_store<8>(p, v, true, bias, n, orow + n);
-            }
-        } else {
+                epilogue_value<8>(p, v, bias, n, orow + n);
+                if (pre) {
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) {
-                const int n = nw0 + ni * 16 + fq * 4;
-                if (n >= p.N) continue;
-                float v[4] = {acc[ni][mi][0], acc[ni][mi][1], acc[ni][mi][2], acc[ni][mi][3]};
-                epilogue_store<4>(p, v, true, bias, n, orow + n);
+                    for (int r = 0; r < 8; ++r) v[r] += rv[q][r];
+                }
+                epilogue_write<8>(p, v, orow + n);
             }
+        }
+        return;
+    }
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int m = mw0 + mi * 16 + fr;
+        if (m >= p.M) continue;
+        const long orow = (long)m * p.o_sW + p.o_c0 + zo;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int n = nw0 + ni * 16 + fq * 4;
+            if (n >= p.N) continue;
+            float v[4] = {acc[ni][mi][0], acc[ni][mi][1], acc[ni][mi][2], acc[ni][mi][3]};
+            epilogue_store<4>(p, v, true, bias, n, orow + n);
         }
     }
 }
@@ -376,10 +427,13 @@ static int launch(const advh_gemm_desc& d, hipStream_t s) {
     const int nz = d.nz > 0 ? d.nz : 1;
     if (d.z_inner && (long)tilesM * tilesN * nz > 0x7fffffffL) return ADVH_EINVAL;
     dim3 grid(d.z_inner ? tilesM * tilesN * nz : tilesM * tilesN, 1, d.z_inner ? 1 : nz);
-    if (BM == 128 && BN == 128 && WPE == 3 && d.plain)
-        hipLaunchKernelGGL((gemm_f16_kernel<BM, BN, WM, WN, WPE, true>), grid, dim3(64 * WM * WN), 0, s, d);
-    else
-        hipLaunchKernelGGL((gemm_f16_kernel<BM, BN, WM, WN, WPE>), grid, dim3(64 * WM * WN), 0, s, d);
+    if constexpr (BM == 128 && BN == 128 && WPE == 3) {
+        if (d.plain) {
+            hipLaunchKernelGGL((gemm_f16_kernel<BM, BN, WM, WN, WPE, true>), grid, dim3(64 * WM * WN), 0, s, d);
+            return ADVH_LAUNCH_CHECK();
+        }
+    }
+    hipLaunchKernelGGL((gemm_f16_kernel<BM, BN, WM, WN, WPE>), grid, dim3(64 * WM * WN), 0, s, d);
     return ADVH_LAUNCH_CHECK();
 }
 
