@@ -10,7 +10,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libaddvisor_hip.so")
+LIB_PATH = os.environ.get("ADDVISOR_HIP_LIB") or os.path.join(_HERE, "libaddvisor_hip.so")   # the override is for A/B runs of two builds
 CSRC = os.path.join(os.path.dirname(_HERE), "csrc")
 
 ERRORS = {-1: "ADVH_EINVAL (bad argument)", -2: "ADVH_ELAUNCH (HIP launch failed)",
