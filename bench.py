@@ -119,7 +119,7 @@ def main():
     n_expl = world * B * args.steps
     value = n_expl / elapsed
     gemm_ms, gemm_flops, gemm_n = G.PROFILE.summary()                      # the tile with the largest total time
-    gemm_kernel = G.TILE_KERNELS.get(getattr(G.PROFILE, "tile", None), "gemm_f16_kernel")
+    gemm_kernel = getattr(G.PROFILE, "kernel", "gemm_f16_kernel")         # the instantiation rocprofv3 lists under this name
     achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else None
     flops_step = pipe.flops(B)
 

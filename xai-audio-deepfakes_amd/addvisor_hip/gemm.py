@@ -60,6 +60,15 @@ class GemmDesc(C.Structure):
     ]
 
 
+def kernel_name(tile: int, plain: bool) -> str:
+    """Name of the kernel instantiation a launch runs, as rocprofv3 prints it (the 256-thread kernels carry the
+    affine-row flag as their last template argument)."""
+    k = TILE_KERNELS.get(tile, "gemm_f16_kernel")
+    if k.startswith("gemm_f16_kernel<"):
+        k = k[:-1] + (", true>" if plain and tile == TILE_128x128 else ", false>")
+    return k
+
+
 class _Profile:
     """Optional live timing of the dominant kernel (the 128x128 tile): HIP events recorded on the launch
     stream around each launch; bench.py reads the totals after a synchronise."""
@@ -70,24 +79,25 @@ class _Profile:
     def reset(self, enabled: bool):
         self.enabled, self.events = enabled, []
 
-    def summary(self, tile=None):
-        """(ms, flops, launches) of ``tile``; default: the tile with the largest total time."""
+    def summary(self, kernel=None):
+        """(ms, flops, launches) of one kernel instantiation (the name rocprofv3 prints, see ``kernel_name``); default: the
+        one with the largest total time, remembered in ``self.kernel``."""
         per = {}
-        for a, b, f, t, _ in self.events:
-            r = per.setdefault(t, [0.0, 0.0, 0])
+        for a, b, f, t, shape in self.events:
+            r = per.setdefault(kernel_name(t, shape[4]), [0.0, 0.0, 0])
             r[0] += a.elapsed_time(b); r[1] += f; r[2] += 1
         if not per:
             return 0.0, 0.0, 0
-        if tile is None:
-            tile = max(per, key=lambda t: per[t][0])
-        self.tile = tile
-        return tuple(per.get(tile, (0.0, 0.0, 0)))
+        if kernel is None:
+            kernel = max(per, key=lambda k: per[k][0])
+        self.kernel = kernel
+        return tuple(per.get(kernel, (0.0, 0.0, 0)))
 
     def by_shape(self):
         """{(M, N, K, nz, tile name): [ms, flops, launches]} of the recorded launches (tools/bench_shapes.py)."""
         per = {}
         for a, b, f, t, shape in self.events:
-            r = per.setdefault(shape + (TILE_NAMES.get(t, str(t)),), [0.0, 0.0, 0])
+            r = per.setdefault(shape[:4] + (TILE_NAMES.get(t, str(t)) + ("+" if shape[4] else ""),), [0.0, 0.0, 0])
             r[0] += a.elapsed_time(b); r[1] += f; r[2] += 1
         return per
 
@@ -298,7 +308,7 @@ class GemmPlan:
         _lib.check(_lib.lib().advh_gemm_f16(C.byref(d), self.tile, stream), "advh_gemm_f16")
         if prof:
             e1.record()
-            PROFILE.events.append((e0, e1, self.flops, self.tile, (self.desc.M, self.desc.N, self.K, self.desc.nz)))
+            PROFILE.events.append((e0, e1, self.flops, self.tile, (self.desc.M, self.desc.N, self.K, self.desc.nz, bool(self.desc.plain))))
 
 
 def _tune(self, d, stream):
