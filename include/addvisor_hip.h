@@ -213,6 +213,13 @@ int advh_w2v2_frontend(const float* wave, int64_t wave_stride, int n_in, int B, 
 int advh_layernorm(const void* in, int in_is_f32, int64_t in_ld, const float* gamma, const float* beta,
                    float* out_f, void* out_h, int64_t out_ld, int M, int C, float eps, int gelu,
                    advh_stream_t stream);
+/* Same with an fp16 addend row: y = LayerNorm(in + add_h) -- the residual add of a post-LN encoder layer
+ * (modeling_wav2vec2.py:689-726: hidden = attn_residual + attention(...); layer_norm(hidden)) fused into the LayerNorm, so
+ * the projection before it stores only its fp16 result instead of reading and re-writing the fp32 stream.  add_h NULL =
+ * advh_layernorm. */
+int advh_layernorm_add(const void* in, int in_is_f32, int64_t in_ld, const void* add_h, int64_t add_ld, const float* gamma,
+                       const float* beta, float* out_f, void* out_h, int64_t out_ld, int M, int C, float eps, int gelu,
+                       advh_stream_t stream);
 
 /* Operand gather of the grouped positional Conv1d (modeling_wav2vec2.py:326-379):
  * h [B][T][H] fp32 -> xg [G][B][T+K][H/G] fp16, data in rows [pad_left, pad_left+T), zeros elsewhere

@@ -44,6 +44,7 @@ SIGNATURES = {
     "advh_gemm_f16": (_i, [_p, _i, _p]),
     "advh_w2v2_frontend": (_i, [_p, _i64, _i, _i, _i, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _i, _i, _i, _p]),
     "advh_layernorm": (_i, [_p, _i, _i64, _p, _p, _p, _p, _i64, _i, _i, _f, _i, _p]),
+    "advh_layernorm_add": (_i, [_p, _i, _i64, _p, _i64, _p, _p, _p, _p, _i64, _i, _i, _f, _i, _p]),
     "advh_posconv_gather": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p, _p]),
     "advh_attention_f16": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "advh_pool_logreg": (_i, [_p, _p, _f, _p, _p, _p, _i, _i, _i, _p]),

@@ -22,6 +22,7 @@ from . import _lib, gemm as G
 from .synthetic import EmbedderConfig
 
 FE_SLACK_ROWS = 4
+BRANCH_F16 = os.environ.get("ADDVISOR_BRANCH_F16", "1") != "0"        # post-LN layers: residual add fused into the LayerNorm
 POSCONV_TILE = os.environ.get("ADDVISOR_POSCONV_TILE", "1") != "0"     # A/B switch: 0 = implicit GEMM for the positional conv
 
 
@@ -41,12 +42,14 @@ class _LN:
         self.g, self.b = _f32(sd[prefix + ".weight"], dev), _f32(sd[prefix + ".bias"], dev)
         self.C = self.g.numel()
 
-    def __call__(self, x: torch.Tensor, M: int, eps: float, out_f=None, out_h=None, gelu=False):
+    def __call__(self, x: torch.Tensor, M: int, eps: float, out_f=None, out_h=None, gelu=False, add_h=None):
+        """``LayerNorm(x [+ add_h])``; ``add_h``: fp16 [M, C] branch output added to the fp32 residual rows first."""
         C = self.C
-        _lib.check(_lib.lib().advh_layernorm(
-            x.data_ptr(), int(x.dtype == torch.float32), C, self.g.data_ptr(), self.b.data_ptr(),
+        _lib.check(_lib.lib().advh_layernorm_add(
+            x.data_ptr(), int(x.dtype == torch.float32), C, None if add_h is None else add_h.data_ptr(), C,
+            self.g.data_ptr(), self.b.data_ptr(),
             None if out_f is None else out_f.data_ptr(), None if out_h is None else out_h.data_ptr(), C, M, C,
-            eps, int(gelu), torch.cuda.current_stream().cuda_stream), "advh_layernorm")
+            eps, int(gelu), torch.cuda.current_stream().cuda_stream), "advh_layernorm_add")
 
 
 class HipEmbedder:
@@ -125,6 +128,7 @@ class HipEmbedder:
         ws["h16"] = torch.empty(M, H, dtype=h16, device=dev)
         ws["qkv"] = torch.empty(M, 3 * H, dtype=h16, device=dev)
         ws["ctx"] = torch.empty(M, H, dtype=h16, device=dev)
+        ws["br"] = torch.empty(M, H, dtype=h16, device=dev)          # fp16 branch output (attention / feed-forward projection)
         ws["ffn"] = torch.empty(M, I, dtype=h16, device=dev)
         K, Gp = cfg.num_conv_pos_embeddings, cfg.num_conv_pos_embedding_groups
         Cg = H // Gp
@@ -248,6 +252,15 @@ class HipEmbedder:
             lay["qkv"].run(h16, out_h=ws["qkv"])
             _lib.check(lib.advh_attention_f16(ws["qkv"].data_ptr(), ws["ctx"].data_ptr(), B, T, H,
                                               cfg.num_attention_heads, st), "advh_attention_f16")
+            if not stable and BRANCH_F16:
+                # post-LN layer: the projection stores its fp16 result only, the residual add happens inside the LayerNorm
+                # (fp32 stream + fp16 branch): the GEMM epilogue neither reads nor re-writes the fp32 rows
+                lay["out"].run(ws["ctx"], out_h=ws["br"])
+                self.ln1[l](h, M, eps, out_f=h, out_h=h16, add_h=ws["br"])
+                lay["ff1"].run(h16, out_h=ws["ffn"])
+                lay["ff2"].run(ws["ffn"], out_h=ws["br"])
+                self.ln2[l](h, M, eps, out_f=h, out_h=h16, add_h=ws["br"])
+                continue
             lay["out"].run(ws["ctx"], out_f=h, resid=h)               # h = h + out_proj(ctx)
             if stable:
                 self.ln2[l](h, M, eps, out_h=h16)

@@ -20,9 +20,11 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 // LayerNorm over the last dim C (C % 4 == 0, C <= 64*4*MAXV): torch.nn.functional.layer_norm semantics
 // (biased variance, eps inside the sqrt); two-pass in registers for accuracy.
-// in: fp32 or fp16 rows; out_f (fp32) and/or out_h (fp16); optional GELU after the affine.
+// in: fp32 or fp16 rows, optionally + an fp16 addend row (residual + branch); out_f (fp32) and/or out_h (fp16);
+// optional GELU after the affine.
 template <bool IN_F32, int MAXV>
 __global__ __launch_bounds__(256) void layernorm_kernel(const void* __restrict__ in, long in_ld,
+                                                        const _Float16* __restrict__ add_h, long add_ld,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         float* __restrict__ out_f, _Float16* __restrict__ out_h, long out_ld,
                                                         int M, int C, float eps, int gelu) {
@@ -42,6 +44,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const void* __restrict__
                 f16x4 t = *(const f16x4*)((const _Float16*)in + row * in_ld + c);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[i][r] = (float)t[r];
+            }
+            if (add_h) {                                  // x = in + branch (the fp16 output of the preceding projection)
+                f16x4 t = *(const f16x4*)(add_h + row * add_ld + c);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[i][r] += (float)t[r];
             }
             s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
         } else {
@@ -191,21 +198,28 @@ __global__ __launch_bounds__(256) void pool_logreg_kernel(const float* __restric
 
 using namespace advh;
 
-extern "C" int advh_layernorm(const void* in, int in_is_f32, int64_t in_ld, const float* gamma, const float* beta,
-                              float* out_f, void* out_h, int64_t out_ld, int M, int C, float eps, int gelu,
-                              advh_stream_t stream) {
-    if (!in || !gamma || !beta || (!out_f && !out_h) || M <= 0 || C <= 0 || C % 4 || in_ld % 4 || out_ld % 4) return ADVH_EINVAL;
+extern "C" int advh_layernorm_add(const void* in, int in_is_f32, int64_t in_ld, const void* add_h, int64_t add_ld,
+                                  const float* gamma, const float* beta, float* out_f, void* out_h, int64_t out_ld, int M, int C,
+                                  float eps, int gelu, advh_stream_t stream) {
+    if (!in || !gamma || !beta || (!out_f && !out_h) || M <= 0 || C <= 0 || C % 4 || in_ld % 4 || out_ld % 4 || (add_h && add_ld % 4))
+        return ADVH_EINVAL;
     if (C > 64 * 4 * 8) return ADVH_EUNSUPPORTED;
     dim3 grid((M + 3) / 4), block(256);
     hipStream_t s = (hipStream_t)stream;
 #define LN_LAUNCH(F32, MV)                                                                                         \
-    hipLaunchKernelGGL((layernorm_kernel<F32, MV>), grid, block, 0, s, in, (long)in_ld, gamma, beta, out_f,        \
-                       (_Float16*)out_h, (long)out_ld, M, C, eps, gelu)
+    hipLaunchKernelGGL((layernorm_kernel<F32, MV>), grid, block, 0, s, in, (long)in_ld, (const _Float16*)add_h,   \
+                       (long)add_ld, gamma, beta, out_f, (_Float16*)out_h, (long)out_ld, M, C, eps, gelu)
     if (C <= 64 * 4 * 2) { if (in_is_f32) LN_LAUNCH(true, 2); else LN_LAUNCH(false, 2); }
     else if (C <= 64 * 4 * 4) { if (in_is_f32) LN_LAUNCH(true, 4); else LN_LAUNCH(false, 4); }
     else { if (in_is_f32) LN_LAUNCH(true, 8); else LN_LAUNCH(false, 8); }
 #undef LN_LAUNCH
     return ADVH_LAUNCH_CHECK();
+}
+
+extern "C" int advh_layernorm(const void* in, int in_is_f32, int64_t in_ld, const float* gamma, const float* beta,
+                              float* out_f, void* out_h, int64_t out_ld, int M, int C, float eps, int gelu,
+                              advh_stream_t stream) {
+    return advh_layernorm_add(in, in_is_f32, in_ld, nullptr, 0, gamma, beta, out_f, out_h, out_ld, M, C, eps, gelu, stream);
 }
 
 extern "C" int advh_posconv_gather(const float* h, void* xg, int B, int T, int H, int G, int K, int pad_left,
