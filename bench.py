@@ -96,7 +96,7 @@ def main():
         pipe.explain(batches[i % n_batches])
     barrier()
 
-    G.PROFILE.reset(enabled=True)
+    G.PROFILE.reset(enabled=os.environ.get("ADDVISOR_BENCH_NO_EVENTS", "0") == "0")     # 1: measure the cost of the per-launch events
     probs = []
     t0 = time.perf_counter()
     for i in range(args.steps):
