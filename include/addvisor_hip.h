@@ -119,7 +119,6 @@ enum { ADVH_TILE_AUTO = 0, ADVH_TILE_128x128 = 1, ADVH_TILE_256x64 = 2, ADVH_TIL
        ADVH_TILE_256x256_RING = 8 /* 512-thread, 32-deep K-tiles in a 4-stage LDS ring */,
        ADVH_TILE_256x128_W8 = 9, ADVH_TILE_128x256_W8 = 10 /* 512-thread single-buffer kernel, 64x64 wave tiles, 2 workgroups per CU */,
        ADVH_TILE_256x256_W4 = 12 /* 256-thread 2-stage ring, 128x128 wave tiles, one wavefront per SIMD */,
-       ADVH_TILE_128x128_O5 = 13 /* the 128x128 tile compiled for five workgroups per CU (<= 96 VGPRs) */,
        ADVH_TILE_256x128_PERSIST = 11 /* persistent 3-stage ring: one workgroup per CU walks tiles, K-steps of consecutive tiles form one DMA stream */ };
 
 typedef struct advh_gemm_desc {

@@ -959,7 +959,6 @@ extern "C" int advh_gemm_f16(const advh_gemm_desc* d, int tile, advh_stream_t st
         case ADVH_TILE_256x128: return launch_pipe<256, 128, 4, 2, 3>(*d, s);
         case ADVH_TILE_256x128_PERSIST: return launch_persist<256, 128, 4, 2>(*d, s);
         case ADVH_TILE_256x256_W4: return launch_pipe<256, 256, 2, 2, 2>(*d, s);
-        case ADVH_TILE_128x128_O5: return launch<128, 128, 2, 2, 5>(*d, s);
         default: return ADVH_EINVAL;
     }
 }
