@@ -214,6 +214,7 @@ __device__ __forceinline__ void gemm_epilogue(const advh_gemm_desc& p, f32x4 (&a
     static_assert(NI % 2 == 0, "the wide epilogue pairs n-tiles");
     const float* bias = p.bias ? p.bias + (long)p.bias_sZ * z : nullptr;
     const RowDecomp rd(p.Wg, p.Hg);
+    const bool oneblk = p.n_div >= p.N && p.ph_r <= 0;
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
         unsigned m = mw0 + mi * 16 + fr;
@@ -232,8 +233,12 @@ __device__ __forceinline__ void gemm_epilogue(const advh_gemm_desc& p, f32x4 (&a
                     int to = (int)w * p.ph_r + n / p.n_div - p.ph_pad;
                     if (to < 0 || to >= p.ph_T) continue;
                 }
-                const int qn = n / p.n_div;
-                long o = orow + (p.n_sub > 1 ? (long)(qn / p.n_sub) * p.o_sNhh + (long)(qn % p.n_sub) * p.o_sNhi : (long)qn * p.o_sNhi) + (n % p.n_div);
+                long o;
+                if (oneblk) o = orow + n;                    // n_div >= N: one column block, no runtime divisions
+                else {
+                    const int qn = n / p.n_div;
+                    o = orow + (p.n_sub > 1 ? (long)(qn / p.n_sub) * p.o_sNhh + (long)(qn % p.n_sub) * p.o_sNhi : (long)qn * p.o_sNhi) + (n % p.n_div);
+                }
                 float v[8];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { v[r] = acc[2 * q][mi][r]; v[4 + r] = acc[2 * q + 1][mi][r]; }
@@ -248,8 +253,12 @@ __device__ __forceinline__ void gemm_epilogue(const advh_gemm_desc& p, f32x4 (&a
                     int to = (int)w * p.ph_r + n / p.n_div - p.ph_pad;
                     if (to < 0 || to >= p.ph_T) continue;
                 }
-                const int qn = n / p.n_div;
-                long o = orow + (p.n_sub > 1 ? (long)(qn / p.n_sub) * p.o_sNhh + (long)(qn % p.n_sub) * p.o_sNhi : (long)qn * p.o_sNhi) + (n % p.n_div);
+                long o;
+                if (oneblk) o = orow + n;
+                else {
+                    const int qn = n / p.n_div;
+                    o = orow + (p.n_sub > 1 ? (long)(qn / p.n_sub) * p.o_sNhh + (long)(qn % p.n_sub) * p.o_sNhi : (long)qn * p.o_sNhi) + (n % p.n_div);
+                }
                 float v[4] = {acc[ni][mi][0], acc[ni][mi][1], acc[ni][mi][2], acc[ni][mi][3]};
                 epilogue_store<4>(p, v, ok, bias, n, o);
             }
