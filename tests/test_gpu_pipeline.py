@@ -28,15 +28,17 @@ def test_explain_tiny_vs_oracle(gpu_device, domain):
     assert (out["wave_out"].cpu() - ref["wave_out"]).abs().max().item() <= 2e-2
 
 
-def test_explain_base_4s_vs_oracle(gpu_device):
-    """BASELINE models (wav2vec2-base + U-Net) on two 4 s clips."""
+@pytest.mark.parametrize("seconds", [4, 5])
+def test_explain_base_4s_vs_oracle(gpu_device, seconds):
+    """BASELINE models (wav2vec2-base + U-Net) on two 4 s clips, and on the reference's default ``audio_length=5``
+    (T = 249 frames, 512 x 248 U-Net grid: SURVEY.md §8 sizes in brackets)."""
     cfg = syn.base_config()
     emb_sd, unet_sd = syn.embedder_weights(cfg), syn.unet_weights()
     coef, icpt = syn.logreg_weights(cfg.hidden_size)
-    pipe = P.ExplainPipeline(cfg, emb_sd, coef, icpt, unet_sd, gpu_device, audio_length=4)
-    w = syn.make_clips(2, 64000)
+    pipe = P.ExplainPipeline(cfg, emb_sd, coef, icpt, unet_sd, gpu_device, audio_length=seconds)
+    w = syn.make_clips(2, 16000 * seconds)
     out = pipe.explain(w.to(gpu_device))
-    ref = lmac_ref.explain(w, emb_sd, cfg, coef, icpt, unet_sd, audio_length=4)
+    ref = lmac_ref.explain(w, emb_sd, cfg, coef, icpt, unet_sd, audio_length=seconds)
     for k in ("predictions", "theta_out", "masked_predictions"):
         err = (out[k].cpu() - ref[k]).abs().max().item()
         print(k, "max err", err, "values", out[k].view(-1).tolist(), ref[k].view(-1).tolist())
