@@ -39,6 +39,11 @@ def test_linear(gpu_device, M, K, N, act):
     y = F.gelu(y) if act == "gelu" else (F.leaky_relu(y, 0.0) if act == "leaky" else y)
     close(out_f, y + res, 2e-4)
     close(out_h, y + res)
+    # fp16 residual (the other branch of the affine-row kernel's lean epilogue) and no residual at all
+    p.run(A, out_f=out_f, resid=res.half().to(gpu_device))
+    close(out_f, y + res.half().float(), 2e-4)
+    p.run(A[:M].contiguous(), out_h=out_h)                       # exactly M rows: the tail tile re-reads row M-1, never past the end
+    close(out_h, y)
 
 
 def test_conv1d_feature_encoder_shape(gpu_device):
