@@ -385,6 +385,21 @@ typedef struct advh_upconv_desc {
 } advh_upconv_desc;
 int advh_upconv21_tile_f16(const advh_upconv_desc* d, advh_stream_t stream);
 int advh_upconv21_tile_lds_bytes(void);
+/* e2.block.0 of the U-Net as a line-tile launch: Conv2d(32, 64, (5,3), stride (2,1), padding (2,1)) + folded BatchNorm +
+ * LeakyReLU (addvisor.py:32).  X [B][2Ho+2PHi][W_+2PWi][32] fp16 zero-haloed (PHi >= 2, PWi >= 1);
+ * W fp16 [15 taps = kh*3+kw][64 rows][32 ci], row R of a tap = output channel 32 (R>>5) + 8 ((R>>2)&3) + 4 ((R>>4)&1) + (R&3);
+ * out_h [B][Ho+2PHo][W_+2PWo][64], interior written (halo must already be zero).                                      */
+typedef struct advh_convs21_desc {
+    const void* X;
+    const void* W;
+    const float* bias;    /* [64] or NULL */
+    void* out_h;
+    int B, Ho, W_, PHi, PWi, PHo, PWo;
+    int act;              /* ADVH_ACT_NONE | ADVH_ACT_LEAKY */
+    float slope;
+} advh_convs21_desc;
+int advh_conv53s21_tile_f16(const advh_convs21_desc* d, advh_stream_t stream);
+int advh_conv53s21_tile_lds_bytes(void);
 int advh_conv_taps_tile(int C, int ntap, int span);       /* positions per workgroup tile (128/192/256); 0 = does not fit */
 int advh_conv_taps_lds_bytes(int C, int ntap, int span);  /* weights + two line buffers; -1 = does not fit           */
 int advh_conv_taps_f16(const advh_taps_desc* d, int C, advh_stream_t stream);

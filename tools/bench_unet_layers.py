@@ -25,6 +25,7 @@ for plan, srcs, dst in ws["steps"]:
     ms = e0.elapsed_time(e1) / 5
     tot += ms
     kind = ("taps2d" if isinstance(plan, G.Taps2dPlan) else "upconv21" if isinstance(plan, G.UpconvTilePlan)
+            else "conv53s21" if isinstance(plan, G.ConvS21TilePlan)
             else G.TILE_NAMES[plan.tile] + ("*" if isinstance(plan, G.PlanGroup) else ""))
     print(f"{'+'.join(srcs):8s} -> {dst:4s} {kind:9s} {ms*1e3:8.1f} us  {plan.flops/ms/1e9:7.1f} TFLOP/s  ({plan.flops/1e9:6.1f} GF)")
 print(f"total GEMM-shaped layers {tot:.3f} ms")

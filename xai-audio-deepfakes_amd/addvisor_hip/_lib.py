@@ -87,6 +87,8 @@ SIGNATURES = {
     "advh_conv_taps2d_f16": (_i, [_p, _i, _p]),
     "advh_upconv21_tile_f16": (_i, [_p, _p]),
     "advh_posconv_tile_f16": (_i, [_p, _p]),
+    "advh_conv53s21_tile_f16": (_i, [_p, _p]),
+    "advh_conv53s21_tile_lds_bytes": (_i, []),
     "advh_posconv_tile_lds_bytes": (_i, [_i, _i]),
     "advh_upconv21_tile_lds_bytes": (_i, []),
 }

@@ -554,6 +554,50 @@ def plan_upconv2d(coarse: FMap, skip: FMap, dst: FMap, wt: torch.Tensor, bt: tor
     return PlanGroup(plans, flops)
 
 
+class ConvS21Desc(C.Structure):
+    _fields_ = [("X", C.c_void_p), ("W", C.c_void_p), ("bias", C.c_void_p), ("out_h", C.c_void_p), ("B", C.c_int),
+                ("Ho", C.c_int), ("W_", C.c_int), ("PHi", C.c_int), ("PWi", C.c_int), ("PHo", C.c_int), ("PWo", C.c_int),
+                ("act", C.c_int), ("slope", C.c_float)]
+
+
+def conv_s21_supported(srcs: Sequence[FMap], dst: FMap, weight: torch.Tensor, stride=(1, 1), padding=(1, 1),
+                       dilation=(1, 1)) -> bool:
+    """Geometry of ``advh_conv53s21_tile_f16``: e2.block.0 of the U-Net (32 -> 64 channels, 5 x 3, stride (2, 1), padding (2, 1))."""
+    return (len(srcs) == 1 and tuple(weight.shape) == (64, 32, 5, 3) and tuple(stride) == (2, 1) and tuple(padding) == (2, 1)
+            and tuple(dilation) == (1, 1) and srcs[0].C == 32 and dst.C == 64 and srcs[0].PH >= 2 and srcs[0].PW >= 1
+            and srcs[0].H == 2 * dst.H and srcs[0].W == dst.W)
+
+
+class ConvS21TilePlan:
+    """e2.block.0 as one LDS line-tile launch (csrc/conv_s21_tile.hip); same ``run`` signature as a GemmPlan."""
+
+    def __init__(self, src: FMap, dst: FMap, weight: torch.Tensor, bias: torch.Tensor, *, slope: float = 0.2, device=None):
+        assert conv_s21_supported([src], dst, weight, (2, 1), (2, 1))
+        R = np.arange(64)
+        ch = 32 * (R >> 5) + 8 * ((R >> 2) & 3) + 4 * ((R >> 4) & 1) + (R & 3)      # MFMA row R carries this output channel
+        wp = weight.float()[torch.from_numpy(ch)].permute(2, 3, 0, 1).reshape(15, 64, 32).to(torch.float16).contiguous()
+        self.w = wp.to(device) if device is not None else wp
+        self.bias = bias.to(torch.float32).contiguous()
+        self.bias = self.bias.to(device) if device is not None else self.bias
+        d = ConvS21Desc()
+        d.B, d.Ho, d.W_ = dst.B, dst.H, dst.W
+        d.PHi, d.PWi, d.PHo, d.PWo = src.PH, src.PW, dst.PH, dst.PW
+        d.act, d.slope = ACT["leaky"], slope
+        self.desc = d
+        self.numels = (src.B * src.Hp * src.Wp * 32, dst.B * dst.Hp * dst.Wp * 64)
+        self.flops = 2.0 * dst.B * dst.H * dst.W * 64 * 32 * 15
+        self.tile = None
+
+    def run(self, A0: torch.Tensor, A1=None, *, out_h: torch.Tensor, stream: Optional[int] = None):
+        d = self.desc
+        for t, n in zip((A0, out_h), self.numels):
+            assert t.dtype == torch.float16 and t.is_cuda and t.is_contiguous() and t.numel() == n
+        d.X, d.W, d.bias, d.out_h = A0.data_ptr(), self.w.data_ptr(), self.bias.data_ptr(), out_h.data_ptr()
+        if stream is None:
+            stream = torch.cuda.current_stream().cuda_stream
+        _lib.check(_lib.lib().advh_conv53s21_tile_f16(C.byref(d), stream), "advh_conv53s21_tile_f16")
+
+
 class UpconvDesc(C.Structure):
     _fields_ = [("Xc", C.c_void_p), ("Xs", C.c_void_p), ("W", C.c_void_p), ("bias", C.c_void_p), ("out_h", C.c_void_p),
                 ("B", C.c_int), ("Hc", C.c_int), ("W_", C.c_int), ("PHc", C.c_int), ("PWc", C.c_int), ("PHs", C.c_int),

@@ -148,6 +148,8 @@ class HipUNet:
             w, b = _fold_bn(sd, conv_name, bn_name)
             if self.line_tile and G.taps2d_supported([m[s] for s in srcs], m[dst], w, **kw):
                 plan = G.Taps2dPlan(m[srcs[0]], m[dst], w, b, slope=SLOPE, device=dev)
+            elif self.line_tile and G.conv_s21_supported([m[s] for s in srcs], m[dst], w, **kw):
+                plan = G.ConvS21TilePlan(m[srcs[0]], m[dst], w, b, slope=SLOPE, device=dev)
             else:
                 plan = G.plan_conv2d([m[s] for s in srcs], m[dst], w, b, slope=SLOPE, device=dev, **kw)
             steps.append((plan, srcs, dst))
