@@ -34,8 +34,12 @@ def test_library_exports_every_symbol(built):
 
 
 def test_code_object_is_gfx950(built):
-    out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "--offloading", built],
-                         capture_output=True, text=True).stdout
+    import shutil
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:               # --offloading writes the extracted bundles next to its input
+        copy = shutil.copy(built, tmp)
+        out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "--offloading", copy],
+                             capture_output=True, text=True, cwd=tmp).stdout
     assert "gfx950" in out
 
 
