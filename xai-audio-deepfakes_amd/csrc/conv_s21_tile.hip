@@ -2,7 +2,7 @@
 // LeakyReLU (addvisor.py:32 with ConvBlock :12-25).  K = 15 taps x 32 channels = 480 and 64 output channels: as an implicit
 // GEMM on the 256 x 64 tile every output re-reads its operand row once per tap through L2 (258 us, 390 TFLOP/s, 2.8x its
 // HBM time).  Here the 15 x 64 x 32 fp16 weights (60 KB) stay resident in LDS and a persistent workgroup streams 8 x 16
-// output tiles through a double-buffered 19 x 18 input patch (27 KB), so HBM traffic = input once (+ halo) + output once.
+// output tiles through a double-buffered 19 x 18 input patch (21.5 KB), so HBM traffic = input once (+ halo) + output once.
 // Weights are the MFMA A operand (rows = output channels, host-permuted so a lane's two accumulator tiles of a pair are 8
 // consecutive channels), positions the B operand; wavefront w owns output rows 2w, 2w+1 of the tile.
 #include <hip/hip_runtime.h>
@@ -23,7 +23,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int S21_CI = 32, S21_CO = 64, S21_KH = 5, S21_KW = 3, S21_NT = S21_KH * S21_KW;   // 15 taps = 15 k-steps of 32
 constexpr int S21_TY = 8, S21_TX = 16;                                                        // output tile
 constexpr int S21_PRW = 2 * (S21_TY - 1) + S21_KH, S21_PCL = S21_TX + S21_KW - 1;             // patch 19 x 18 pixels
-constexpr int S21_SLOTS = 5, S21_PITCH = S21_SLOTS * 16;                                      // 4 chunks + 1 pad: conflict-free rows
+constexpr int S21_SLOTS = 4, S21_PITCH = S21_SLOTS * 16;                                      // 64-byte pixels, chunk c at slot c ^ ((pixel >> 1) & 2)
 constexpr int S21_WBYTES = S21_NT * S21_CO * 64;                                              // 61 440
 constexpr int S21_PCH = (S21_PRW * S21_PCL * S21_SLOTS + 63) & ~63;                           // patch chunks (whole-wave loads)
 
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void conv53s21_tile_kernel(const advh_convs21_
             if (pix >= S21_PRW * S21_PCL) pix = 0;
             // patch row 0 = input row 2 y0 - 2, column 0 = x0 - 1 (padded coordinates, clamped: clamped pixels only feed skipped outputs)
             const int gy = min(2 * y0 + p.PHi - 2 + pix / S21_PCL, Hpi - 1), gx = min(x0 + p.PWi - 1 + pix % S21_PCL, Wpi - 1);
-            const _Float16* src = X + (((long)b * Hpi + gy) * Wpi + gx) * S21_CI + (slot < 4 ? slot : 0) * 8;
+            const _Float16* src = X + (((long)b * Hpi + gy) * Wpi + gx) * S21_CI + ((slot ^ (((i / S21_SLOTS) >> 1) & 2)) * 8);
             __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src), LDS_PTR(dst + (size_t)(i - lane) * 16), 16, 0, 0);
         }
     };
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void conv53s21_tile_kernel(const advh_convs21_
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tile + (int)gridDim.x < ntiles) load_patch(tile + gridDim.x, buf ^ 1);
-        const unsigned xl = lds0 + S21_WBYTES + (unsigned)buf * S21_PCH * 16 + (unsigned)(g * 16);
+        const unsigned xl = lds0 + S21_WBYTES + (unsigned)buf * S21_PCH * 16;
         f32x4 acc[4][2];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -84,7 +84,8 @@ __global__ __launch_bounds__(256) void conv53s21_tile_kernel(const advh_convs21_
             for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         auto xaddr = [&](int s, int j) {                             // tap s = kh * 3 + kw, output row 2 wv + j of the tile
             const int kh = s / S21_KW, kw = s - kh * S21_KW;
-            return xl + (unsigned)(((2 * (2 * wv + j) + kh) * S21_PCL + kw + fr) * S21_PITCH);
+            const int pix = (2 * (2 * wv + j) + kh) * S21_PCL + kw + fr;
+            return xl + (unsigned)(pix * S21_PITCH + ((g ^ ((pix >> 1) & 2)) * 16));
         };
         f16x8 wf[2][4], xf[2][2];
 #pragma unroll

@@ -31,12 +31,14 @@ constexpr int PC_K = 128, PC_RING = 3, PC_BLK = 4;               // taps; ring s
 // One weight block (PC_BLK k-steps) for a wavefront that owns NJ frame tiles: the operands of k-step ks+1 are read from
 // LDS between the MFMAs of k-step ks (register double buffer), so only the first reads of a block are exposed.
 template <int CC, int NJ>
-__device__ __forceinline__ void posconv_block(f32x4 (&acc)[4][CC / 2], unsigned wb, const unsigned (&xrow)[4], int& cc, unsigned& xoff) {
-    constexpr int CG = CC * 8, NI = CG / 16, PITCH = (CC + 1) * 16, NR = NI + NJ;
+__device__ __forceinline__ void posconv_block(f32x4 (&acc)[4][CC / 2], unsigned wb, const unsigned (&xrow)[4], int& cc, int& tap, int fr) {
+    constexpr int CG = CC * 8, NI = CG / 16, PITCH = 128, NR = NI + NJ;
+    // byte offset of (tap, chunk cc) relative to the lane's frame row: row + tap, slot cc ^ ((row + tap) & 7); 16 mt is a multiple of 8
+    auto xo_of = [&](int c, int t) { return (unsigned)(t * PITCH + ((c ^ ((fr + t) & 7)) << 4)); };
     if constexpr (NJ > 0) {
         f16x8 wf[2][NI], xf[2][NJ];
         unsigned xo[2];
-        xo[0] = xoff;
+        xo[0] = xo_of(cc, tap);
 #pragma unroll
         for (int i = 0; i < NI; ++i) DS_READ128(wf[0][i], wb, i * 16 * 64);
 #pragma unroll
@@ -45,9 +47,8 @@ __device__ __forceinline__ void posconv_block(f32x4 (&acc)[4][CC / 2], unsigned 
         for (int ks = 0; ks < PC_BLK; ++ks) {
             const int cur = ks & 1, nxt = cur ^ 1;
             cc += 4;
-            xoff += 64;
-            if (cc >= CC) { cc -= CC; xoff += PITCH - CC * 16; }
-            xo[nxt] = xoff;
+            if (cc >= CC) { cc -= CC; ++tap; }
+            xo[nxt] = xo_of(cc, tap);
             const unsigned wn = wb + (unsigned)((ks + 1) * CG * 64);
             LGKM_WAIT(0);
             __builtin_amdgcn_sched_barrier(0);
@@ -73,15 +74,14 @@ __device__ __forceinline__ void posconv_block(f32x4 (&acc)[4][CC / 2], unsigned 
 #pragma unroll
         for (int ks = 0; ks < PC_BLK; ++ks) {
             cc += 4;
-            xoff += 64;
-            if (cc >= CC) { cc -= CC; xoff += PITCH - CC * 16; }
+            if (cc >= CC) { cc -= CC; ++tap; }
         }
     }
 }
 
 template <int CC>                                                // 16-byte chunks per row = channels per group / 8 (6 or 8)
 __global__ __launch_bounds__(256, 2) void posconv_tile_kernel(const advh_posconv_desc p) {
-    constexpr int CG = CC * 8, NI = CG / 16, SLOTS = CC + 1, PITCH = SLOTS * 16;   // odd slot count: conflict-free row reads
+    constexpr int CG = CC * 8, NI = CG / 16, SLOTS = 8, PITCH = SLOTS * 16;   // 128-byte rows, chunk c at slot c ^ (row & 7) as in the GEMM tiles
     constexpr int KSTEPS = PC_K * CC / 4, NBLK = KSTEPS / PC_BLK, WBLK = PC_BLK * CG * 64, WL = WBLK / 16 / 256, MT = 4;
     static_assert(WBLK % (256 * 16) == 0 && KSTEPS % PC_BLK == 0, "weight block = whole loads per thread");
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -102,7 +102,8 @@ __global__ __launch_bounds__(256, 2) void posconv_tile_kernel(const advh_posconv
             int row = i / SLOTS;
             const int slot = i - row * SLOTS;
             if (row >= rows) row = 0;
-            const _Float16* src = xs + (long)row * CG + (slot < CC ? slot : 0) * 8;    // slot CC is padding
+            const int c = slot ^ ((i / SLOTS) & 7);                 // LDS slot -> logical chunk (slots holding c >= CC are padding)
+            const _Float16* src = xs + (long)row * CG + (c < CC ? c : 0) * 8;
             __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src), LDS_PTR(Xl + (size_t)(i - lane) * 16), 16, 0, 0);
         }
         auto issue_w = [&](int blk) {                            // [4 k-steps][CG rows][32 k] -> 64-byte LDS rows, swizzled
@@ -123,8 +124,7 @@ __global__ __launch_bounds__(256, 2) void posconv_tile_kernel(const advh_posconv
 #pragma unroll
             for (int i = 0; i < NI; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
         // this lane group's chunk of k-step s is 4 s + g -> (tap, chunk-in-row); kept as a byte offset into the staged clip
-        int cc = g;                                              // g < 4 <= CC: tap 0
-        unsigned xoff = (unsigned)(g * 16);
+        int cc = g, tap = 0;                                     // g < 4 <= CC: tap 0
         const unsigned lds0 = (unsigned)(unsigned long)LDS_PTR(lds);
         unsigned xrow[MT];
 #pragma unroll
@@ -138,11 +138,11 @@ __global__ __launch_bounds__(256, 2) void posconv_tile_kernel(const advh_posconv
             if (blk + 2 < NBLK) issue_w(blk + 2);
             const unsigned wb = wlane + (unsigned)(blk % PC_RING) * WBLK;
             switch (nj) {
-                case 4: posconv_block<CC, 4>(acc, wb, xrow, cc, xoff); break;
-                case 3: posconv_block<CC, 3>(acc, wb, xrow, cc, xoff); break;
-                case 2: posconv_block<CC, 2>(acc, wb, xrow, cc, xoff); break;
-                case 1: posconv_block<CC, 1>(acc, wb, xrow, cc, xoff); break;
-                default: posconv_block<CC, 0>(acc, wb, xrow, cc, xoff); break;
+                case 4: posconv_block<CC, 4>(acc, wb, xrow, cc, tap, fr); break;
+                case 3: posconv_block<CC, 3>(acc, wb, xrow, cc, tap, fr); break;
+                case 2: posconv_block<CC, 2>(acc, wb, xrow, cc, tap, fr); break;
+                case 1: posconv_block<CC, 1>(acc, wb, xrow, cc, tap, fr); break;
+                default: posconv_block<CC, 0>(acc, wb, xrow, cc, tap, fr); break;
             }
         }
         // h[b][t][grp*CG + 16 i + 4 g + r] += GELU(acc + bias)
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256, 2) void posconv_tile_kernel(const advh_posconv
 }
 
 template <int CC> static int pc_lds_bytes(int T) {
-    const int rows = T + PC_K - 1, nX = (rows * (CC + 1) + 63) & ~63;
+    const int rows = T + PC_K - 1, nX = (rows * 8 + 63) & ~63;             // 8 slots per staged row
     return PC_RING * PC_BLK * CC * 8 * 64 + nX * 16;
 }
 
