@@ -179,7 +179,8 @@ using namespace advh;
 
 extern "C" int advh_posconv_tile_lds_bytes(int Cg, int T) {
     if (T <= 0 || T > 256) return -1;
-    return Cg == 48 ? pc_lds_bytes<6>(T) : (Cg == 64 ? pc_lds_bytes<8>(T) : -1);
+    const int b = Cg == 48 ? pc_lds_bytes<6>(T) : (Cg == 64 ? pc_lds_bytes<8>(T) : -1);
+    return b <= 160 * 1024 ? b : -1;
 }
 
 extern "C" int advh_posconv_tile_f16(const advh_posconv_desc* d, advh_stream_t stream) {
