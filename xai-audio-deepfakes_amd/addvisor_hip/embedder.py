@@ -160,7 +160,9 @@ class HipEmbedder:
         # line-tile launch for the same layer (csrc/posconv_tile.hip): the clip's gathered rows staged in LDS once, the
         # group's weights streamed; the implicit GEMM above stays as the fallback for other geometries
         ws["pos_tile"] = None
-        if POSCONV_TILE and _lib.lib().advh_posconv_tile_lds_bytes(Cg, T) > 0 and K == 128:
+        # (64-channel groups leave room for one workgroup per CU only: measured 308 vs 369 us at 64 clips but 925 vs 876 us
+        # at 192 -- tools/bench_posconv.py -- so large models switch back to the GEMM for big batches)
+        if POSCONV_TILE and _lib.lib().advh_posconv_tile_lds_bytes(Cg, T) > 0 and K == 128 and (Cg <= 48 or B <= 96):
             if "pos_tile" not in self._wcache:
                 wt = w2().view(Gp, Cg, K * Cg // 32, 32).permute(0, 2, 1, 3).contiguous().to(torch.float16)   # [g][k-step][n][32]
                 self._wcache["pos_tile"] = (wt.to(dev), sd["encoder.pos_conv_embed.conv.bias"].float().contiguous().to(dev))
