@@ -204,9 +204,11 @@ __global__ __launch_bounds__(256) void conv_taps_kernel(const advh_taps_desc p) 
 // (kh, kw) of output (ly, lx) is the patch row (ly + kh) * 18 + lx + kw: again a constant row offset.  Wavefront w owns
 // tile rows 4w .. 4w+3 (one 16-position column tile each).  Only interior positions are written; the destination's halo
 // stays as allocated (zero).
-template <int C>
-__global__ __launch_bounds__(256) void conv_taps2d_kernel(const advh_taps2d_desc p) {
-    constexpr int CH = C / 8, CT = C / 16, KS = C / 32, NJ = 4, PR = 18, SR = PR * PR;
+// NW wavefronts per workgroup: each owns 16 / NW rows of the 16 x 16 tile (NW = 8 for the 64-channel instance, whose 156 KB of
+// LDS allow one workgroup per CU: eight wavefronts hide the LDS / store latency four could not)
+template <int C, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void conv_taps2d_kernel(const advh_taps2d_desc p) {
+    constexpr int CH = C / 8, CT = C / 16, KS = C / 32, NJ = 16 / NW, NTH = 64 * NW, PR = 18, SR = PR * PR;
     constexpr int SRC = (SR * CH + 63) & ~63;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -214,7 +216,7 @@ __global__ __launch_bounds__(256) void conv_taps2d_kernel(const advh_taps2d_desc
     char* Wl = lds;
     char* Xl = lds + 9 * C * C * 2;
     const _Float16* Wg = (const _Float16*)p.W;
-    for (int i = tid; i < 9 * C * CH; i += 256) {
+    for (int i = tid; i < 9 * C * CH; i += NTH) {
         int row = i / CH, pos = i % CH;
         const _Float16* src = Wg + ((long)(row / C) * C + cout_of(row % C)) * C + ((pos ^ swz<C>(row)) * 8);
         __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src), LDS_PTR(Wl + (size_t)(i - lane) * 16), 16, 0, 0);
@@ -232,7 +234,7 @@ __global__ __launch_bounds__(256) void conv_taps2d_kernel(const advh_taps2d_desc
         int b, y0, x0;
         origin(tile, b, y0, x0);
         char* dst = Xl + (size_t)buf * SRC * 16;
-        for (int i = tid; i < SRC; i += 256) {
+        for (int i = tid; i < SRC; i += NTH) {
             int row = i / CH, pos = i % CH;
             if (row >= SR) row = 0;
             // padded coordinates of patch row `row`, clamped into the map (clamped rows only feed skipped outputs)
@@ -378,7 +380,7 @@ extern "C" int advh_conv_taps2d_f16(const advh_taps2d_desc* d, int C, advh_strea
     const int lds = 9 * C * C * 2 + 2 * ((18 * 18 * (C / 8) + 63) / 64 * 64) * 16;
     static bool attr[2] = {false, false};
     const int ci = C == 64;
-    const void* fn = ci ? (const void*)conv_taps2d_kernel<64> : (const void*)conv_taps2d_kernel<32>;
+    const void* fn = ci ? (const void*)conv_taps2d_kernel<64, 8> : (const void*)conv_taps2d_kernel<32>;
     if (!attr[ci]) {
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return ADVH_ELAUNCH;
         attr[ci] = true;
@@ -387,7 +389,7 @@ extern "C" int advh_conv_taps2d_f16(const advh_taps2d_desc* d, int C, advh_strea
     const int per_cu = lds <= 80 * 1024 ? 2 : 1;
     long grid = 256L * per_cu;
     if (grid > ntiles) grid = ntiles;
-    if (ci) hipLaunchKernelGGL(conv_taps2d_kernel<64>, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, *d);
+    if (ci) hipLaunchKernelGGL((conv_taps2d_kernel<64, 8>), dim3((unsigned)grid), dim3(512), lds, (hipStream_t)stream, *d);
     else hipLaunchKernelGGL(conv_taps2d_kernel<32>, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, *d);
     return ADVH_LAUNCH_CHECK();
 }
