@@ -28,10 +28,10 @@ constexpr int RB_TC = 256;                 // conv1 positions per tile
 constexpr int RB_TMROWS = RB_TC + 16;      // rows of the intermediate tile (conv2 taps of masked outputs may run past 256)
 
 // acc[i][j] += sum over taps t and channels of W[t][16 i + ..][..] * rows[row0 + 16 j + fr + t * dil][..]
-template <int C>
+template <int C, int NJ>
 __device__ __forceinline__ void taps_mma(unsigned wbase, unsigned xbase, int row0, int ntap, int dil, int fr, int g,
-                                         f32x4 (&acc)[C / 16][4]) {
-    constexpr int CH = C / 8, CT = C / 16, KS = C / 32, NJ = 4;
+                                         f32x4 (&acc)[C / 16][NJ]) {
+    constexpr int CH = C / 8, CT = C / 16, KS = C / 32;
     const int NS = ntap * KS;
     auto addr = [&](int s, unsigned& wa, unsigned& xa) {
         const int t = s / KS, c = (s % KS) * 4 + g;
@@ -75,9 +75,11 @@ __device__ __forceinline__ void taps_mma(unsigned wbase, unsigned xbase, int row
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int C>
-__global__ __launch_bounds__(256) void resblock_pair_kernel(const advh_resblock_desc p, int nbuf) {
-    constexpr int CH = C / 8, CT = C / 16, NJ = 4;
+// NJ = 16-position column tiles per wavefront; 256 / (16 NJ) wavefronts per workgroup (NJ = 2: eight wavefronts for the 64-channel
+// instance, which mostly runs one workgroup per CU)
+template <int C, int NJ = 4>
+__global__ __launch_bounds__(64 * (16 / NJ)) void resblock_pair_kernel(const advh_resblock_desc p, int nbuf) {
+    constexpr int CH = C / 8, CT = C / 16, NTH = 64 * (16 / NJ), WP = 16 * NJ;      // threads; positions per wavefront
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int fr = lane & 15, g = lane >> 4;
@@ -96,7 +98,7 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(const advh_resblock_
     for (int which = 0; which < 2; ++which) {                       // both weight tensors: once per workgroup, rows permuted (rcout_of)
         const _Float16* Wg = (const _Float16*)(which ? p.W2 : p.W1);
         char* Wl = which ? W2 : W1;
-        for (int i = tid; i < k * C * CH; i += 256) {
+        for (int i = tid; i < k * C * CH; i += NTH) {
             const int row = i / CH, pos = i % CH;
             const _Float16* src = Wg + ((long)(row / C) * C + rcout_of(row % C)) * C + ((pos ^ rswz<C>(row)) * 8);
             __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src), LDS_PTR(Wl + (size_t)(i - lane) * 16), 16, 0, 0);
@@ -106,7 +108,7 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(const advh_resblock_
     auto load_lines = [&](int tile, int buf) {                      // rows tile*TO - h2 - h1 .. + SR, clamped into the map
         const long r0 = (long)tile * TO - h2 - h1;
         char* dst = XR + (size_t)buf * SRC * 16;
-        for (int i = tid; i < SRC; i += 256) {
+        for (int i = tid; i < SRC; i += NTH) {
             const int row = i / CH, pos = i % CH;
             long r = r0 + row;
             r = r < 0 ? 0 : (r >= p.M ? p.M - 1 : r);
@@ -146,7 +148,7 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(const advh_resblock_
         f16x8 res[CT / 2][NJ];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            const int row = wv * 64 + j * 16 + fr + h1 + h2;        // output o = wv*64 + j*16 + fr sits at line-buffer row o + h1 + h2
+            const int row = wv * WP + j * 16 + fr + h1 + h2;        // output o = wv*64 + j*16 + fr sits at line-buffer row o + h1 + h2
 #pragma unroll
             for (int q = 0; q < CT / 2; ++q)
                 res[q][j] = *(const f16x8*)(xb + ((size_t)row * CH + ((4 * q + g) ^ rswz<C>(row))) * 16);
@@ -154,7 +156,7 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(const advh_resblock_
         __syncthreads();
         {
             const _Float16 sl = (_Float16)p.slope;
-            for (int i = tid; i < SRC; i += 256) {
+            for (int i = tid; i < SRC; i += NTH) {
                 f16x8 v = *(f16x8*)(xb + (size_t)i * 16);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = v[e] > (_Float16)0 ? v[e] : v[e] * sl;
@@ -168,13 +170,13 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(const advh_resblock_
         for (int i = 0; i < CT; ++i)
 #pragma unroll
             for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        taps_mma<C>(w1a, xra + (unsigned)buf * SRC * 16, wv * 64, k, d, fr, g, acc);
+        taps_mma<C, NJ>(w1a, xra + (unsigned)buf * SRC * 16, wv * WP, k, d, fr, g, acc);
         __syncthreads();                                            // every wavefront has read its lines: the buffer becomes the intermediate tile
         if (tid < (RB_TMROWS - RB_TC) * CH)                         // rows past 256 only feed masked outputs, but must be finite
             *(f16x8*)(TM + ((size_t)RB_TC * CH + tid) * 16) = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            const int c = wv * 64 + j * 16 + fr;
+            const int c = wv * WP + j * 16 + fr;
             const bool ok = in_clip(base - h2 + c);
 #pragma unroll
             for (int q = 0; q < CT / 2; ++q) {
@@ -195,10 +197,10 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(const advh_resblock_
         for (int i = 0; i < CT; ++i)
 #pragma unroll
             for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        taps_mma<C>(w2a, tma, wv * 64, k, 1, fr, g, acc);
+        taps_mma<C, NJ>(w2a, tma, wv * WP, k, 1, fr, g, acc);
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            const int o = wv * 64 + j * 16 + fr;
+            const int o = wv * WP + j * 16 + fr;
             const long m = base + o;
             if (o >= TO || m >= p.M) continue;
             const bool ok = in_clip(m);
@@ -248,7 +250,7 @@ extern "C" int advh_resblock_pair_f16(const advh_resblock_desc* d, int C, advh_s
     if (lds > 160 * 1024 || (d->k - 1) / 2 * 2 >= RB_TC / 2) return ADVH_EUNSUPPORTED;
     static bool attr[2] = {false, false};
     const int ci = C == 64;
-    const void* fn = ci ? (const void*)resblock_pair_kernel<64> : (const void*)resblock_pair_kernel<32>;
+    const void* fn = ci ? (const void*)resblock_pair_kernel<64, 2> : (const void*)resblock_pair_kernel<32>;
     if (!attr[ci]) {
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return ADVH_ELAUNCH;
         attr[ci] = true;
@@ -257,7 +259,7 @@ extern "C" int advh_resblock_pair_f16(const advh_resblock_desc* d, int C, advh_s
     const int ntiles = (d->M + TO - 1) / TO;
     int grid = 256 * (lds <= 80 * 1024 ? 2 : 1);
     if (grid > ntiles) grid = ntiles;
-    if (ci) hipLaunchKernelGGL(resblock_pair_kernel<64>, dim3(grid), dim3(256), lds, (hipStream_t)stream, *d, nbuf);
+    if (ci) hipLaunchKernelGGL((resblock_pair_kernel<64, 2>), dim3(grid), dim3(512), lds, (hipStream_t)stream, *d, nbuf);
     else hipLaunchKernelGGL(resblock_pair_kernel<32>, dim3(grid), dim3(256), lds, (hipStream_t)stream, *d, nbuf);
     return ADVH_LAUNCH_CHECK();
 }
