@@ -36,9 +36,9 @@ __device__ __forceinline__ int cout_of(int R) { return ((R >> 5) << 5) + (((R >>
 
 // NJ = 16-position column tiles per wavefront; a workgroup (4 wavefronts) owns TT = 64 * NJ positions per tile.
 // The line buffer is double-buffered: the DMA of tile i+1 runs under the MFMAs and the stores of tile i.
-template <int C, int NJ>
-__global__ __launch_bounds__(256) void conv_taps_kernel(const advh_taps_desc p) {
-    constexpr int CH = C / 8, CT = C / 16, KS = C / 32, TT = 64 * NJ;
+template <int C, int NJ, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void conv_taps_kernel(const advh_taps_desc p) {
+    constexpr int CH = C / 8, CT = C / 16, KS = C / 32, TT = 16 * NJ * NW, NTH = 64 * NW;   // NW wavefronts x NJ column tiles of 16 positions
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int fr = lane & 15, g = lane >> 4;
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void conv_taps_kernel(const advh_taps_desc p) 
 
     // ---- weights: once per workgroup
     const _Float16* Wg = (const _Float16*)p.W;
-    for (int i = tid; i < p.ntap * C * CH; i += 256) {             // i = lds chunk index (wave-linear)
+    for (int i = tid; i < p.ntap * C * CH; i += NTH) {             // i = lds chunk index (wave-linear)
         int row = i / CH, pos = i % CH;
         const _Float16* src = Wg + ((long)(row / C) * C + cout_of(row % C)) * C + ((pos ^ swz<C>(row)) * 8);
         __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src), LDS_PTR(Wl + (size_t)(i - lane) * 16), 16, 0, 0);
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void conv_taps_kernel(const advh_taps_desc p) 
     auto load_lines = [&](int tile, int buf) {
         const long p0 = (long)tile * TT + lo;
         char* dst = Xl + (size_t)buf * SRC * 16;
-        for (int i = tid; i < SRC; i += 256) {
+        for (int i = tid; i < SRC; i += NTH) {
             int row = i / CH, pos = i % CH;
             long r = p0 + row;
             r = r < 0 ? 0 : (r >= p.M ? p.M - 1 : r);
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void conv_taps_kernel(const advh_taps_desc p) 
             // path needs it anyway) instead of a second, pre-activated copy -- one map write and one map read less
             char* xb = Xl + (size_t)buf * SRC * 16;
             const _Float16 sl = (_Float16)p.pre_slope;
-            for (int i = tid; i < SRC; i += 256) {
+            for (int i = tid; i < SRC; i += NTH) {
                 f16x8 v = *(f16x8*)(xb + (size_t)i * 16);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = v[j] > (_Float16)0 ? v[j] : v[j] * sl;
@@ -358,7 +358,7 @@ extern "C" int advh_conv_taps_f16(const advh_taps_desc* d, int C, advh_stream_t 
     const int nj = tt / 64, lds = taps_lds(C, d->ntap, span, nj);
     typedef void (*kern_t)(const advh_taps_desc);
     static const kern_t kerns[2][3] = {{conv_taps_kernel<32, 2>, conv_taps_kernel<32, 3>, conv_taps_kernel<32, 4>},
-                                       {conv_taps_kernel<64, 2>, conv_taps_kernel<64, 3>, conv_taps_kernel<64, 4>}};
+                                       {conv_taps_kernel<64, 2>, conv_taps_kernel<64, 3>, conv_taps_kernel<64, 2, 8>}};   // 256-position tile: eight wavefronts
     static bool attr[2][3] = {{false, false, false}, {false, false, false}};
     const int ci = C == 64, ji = nj - 2;
     if (!attr[ci][ji]) {
@@ -369,7 +369,7 @@ extern "C" int advh_conv_taps_f16(const advh_taps_desc* d, int C, advh_stream_t 
     const int per_cu = lds <= 40 * 1024 ? 4 : (lds <= 53 * 1024 ? 3 : (lds <= 80 * 1024 ? 2 : 1));
     int grid = 256 * per_cu;
     if (grid > ntiles) grid = ntiles;
-    hipLaunchKernelGGL(kerns[ci][ji], dim3(grid), dim3(256), lds, (hipStream_t)stream, *d);
+    hipLaunchKernelGGL(kerns[ci][ji], dim3(grid), dim3(ci && nj == 4 ? 512 : 256), lds, (hipStream_t)stream, *d);
     return ADVH_LAUNCH_CHECK();
 }
 
