@@ -358,7 +358,7 @@ extern "C" int advh_conv_taps_f16(const advh_taps_desc* d, int C, advh_stream_t 
     const int nj = tt / 64, lds = taps_lds(C, d->ntap, span, nj);
     typedef void (*kern_t)(const advh_taps_desc);
     static const kern_t kerns[2][3] = {{conv_taps_kernel<32, 2>, conv_taps_kernel<32, 3>, conv_taps_kernel<32, 4>},
-                                       {conv_taps_kernel<64, 2>, conv_taps_kernel<64, 3>, conv_taps_kernel<64, 2, 8>}};   // 256-position tile: eight wavefronts
+                                       {conv_taps_kernel<64, 2>, conv_taps_kernel<64, 2, 6>, conv_taps_kernel<64, 2, 8>}};   // 192 / 256 positions: six / eight wavefronts of two column tiles
     static bool attr[2][3] = {{false, false, false}, {false, false, false}};
     const int ci = C == 64, ji = nj - 2;
     if (!attr[ci][ji]) {
@@ -369,7 +369,7 @@ extern "C" int advh_conv_taps_f16(const advh_taps_desc* d, int C, advh_stream_t 
     const int per_cu = lds <= 40 * 1024 ? 4 : (lds <= 53 * 1024 ? 3 : (lds <= 80 * 1024 ? 2 : 1));
     int grid = 256 * per_cu;
     if (grid > ntiles) grid = ntiles;
-    hipLaunchKernelGGL(kerns[ci][ji], dim3(grid), dim3(ci && nj == 4 ? 512 : 256), lds, (hipStream_t)stream, *d);
+    hipLaunchKernelGGL(kerns[ci][ji], dim3(grid), dim3(ci && nj == 4 ? 512 : (ci && nj == 3 ? 384 : 256)), lds, (hipStream_t)stream, *d);
     return ADVH_LAUNCH_CHECK();
 }
 
