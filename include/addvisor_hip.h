@@ -186,6 +186,16 @@ typedef struct advh_gemm_desc {
        o_c0 + m * o_sW + the batch offset and the columns are one block (n_div >= N, no phases, no sub-pixel split):
        the epilogue skips the row decomposition and the column divisions.                                          */
     int32_t plain_out;
+    /* split = 1: fp32-class mode.  Every fp16 operand and fp16 output is a PAIR of planes (hi, lo) in the split format
+       x = hi + lo * 2^-11 (csrc/device_math.h: hi = fp16(x), lo = fp16((x - hi) * 2^11)); the lo plane of source s starts
+       a_lo[s] chunks behind A_s, that of W w_lo elements behind W, that of out_h / out_h2 / a fp16 resid o_lo elements
+       behind the hi plane, all addressed like the hi plane.  The kernel issues three MFMAs per fragment pair
+       (Wh*Ah + (Wh*Al + Wl*Ah) * 2^-11, fp32 accumulate): the arithmetic class of the reference's fp32 layers.
+       Tiles: 128x128, 256x64, 256x32 (AUTO picks as for fp16); out_pre / dact_src are not supported.              */
+    int32_t split;
+    int64_t a_lo[2];
+    int64_t w_lo;
+    int64_t o_lo;
 } advh_gemm_desc;
 
 int advh_gemm_f16(const advh_gemm_desc* desc, int tile, advh_stream_t stream);
@@ -328,6 +338,33 @@ int advh_scale_rows(const float* x, int x_rows, const float* alpha, float* y, in
 int advh_attr_finalize(const float* g, const float* x, float* out, int mode, int64_t total, advh_stream_t stream);
 int advh_time_mask(const float* attr, float* mask, float* wave_in, float* wave_out, const float* wave, int B, int64_t n,
                    advh_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * fp32-class ("split") mode.  The reference computes the whole path in fp32 (addvisor.py:12-84,
+ * transformers/models/wav2vec2/modeling_wav2vec2.py:254-802 under audioprocessor.py:69-77).  In this mode every tensor
+ * that the fp16 path stores as fp16 is a PAIR of fp16 planes (hi, lo) with x = hi + lo * 2^-11 (hi = fp16(x),
+ * lo = fp16((x - hi) * 2^11); csrc/device_math.h) -- ~22 significand bits -- and every matrix product runs as three fp16
+ * MFMAs with fp32 accumulation (advh_gemm_desc.split).  The entry points below are the split-format variants of the row /
+ * direct kernels above: same arithmetic, `*_lo` = distance in ELEMENTS from a tensor's hi plane to its lo plane (both planes
+ * share one addressing).  fp32 tensors (residual stream, masks, waveforms, statistics) are unchanged.                     */
+int advh_w2v2_frontend_split(const float* wave, int64_t wave_stride, int n_in, int B, int L, const float* w0,
+                             const float* bias0, const float* gamma, const float* beta, int mode, int normalize, float* stats_ws,
+                             float* norm_ws, float* mr_ws, void* out, int64_t out_lo, int T0, int P0, int C0, advh_stream_t stream);
+/* in: fp32 rows (in_is_f32, in_lo ignored) or a split pair; add_h: NULL or a split pair; out_h: NULL or a split pair. */
+int advh_layernorm_split(const void* in, int in_is_f32, int64_t in_ld, int64_t in_lo, const void* add_h, int64_t add_ld,
+                         int64_t add_lo, const float* gamma, const float* beta, float* out_f, void* out_h, int64_t out_ld,
+                         int64_t out_lo, int M, int C, float eps, int gelu, advh_stream_t stream);
+int advh_posconv_gather_split(const float* h, void* xg, int64_t xg_lo, int B, int T, int H, int G, int K, int pad_left,
+                              advh_stream_t stream);
+/* softmax(Q K^T / sqrt(d)) V on split q | k | v -> split ctx; T <= 256, head dim <= 64 (a multiple of 8). */
+int advh_attention_split(const void* qkv, int64_t qkv_lo, void* ctx, int64_t ctx_lo, int B, int T, int H, int heads,
+                         advh_stream_t stream);
+int advh_unet_stem_split(const float* mag, int Fq, int Tq, int B, int H, int W, const float* wgt, const float* bias,
+                         void* out, int64_t out_lo, int PH, int PW, float slope, advh_stream_t stream);
+int advh_unet_pack_x_split(const float* mag, int Fq, int Tq, int B, int H, int W, void* cat, int64_t cat_lo, int C, int c0,
+                           int PH, int PW, advh_stream_t stream);
+int advh_unet_head_split(const void* y, int64_t y_lo, int B, int H, int W, int PH, int PW, const float* wgt, float bias,
+                         float* mask, float* logits, advh_stream_t stream);
 
 /* ---- LDS line-tile convolution for narrow layers (C_in = C_out = C in {32, 64}) -------------------------------
  * out[m][co] = act(bias[co] + sum_t sum_ci W[t][co][ci] * X[m + toff[t]][ci]) (+ resid[m][co]) over the M rows of a

@@ -19,8 +19,12 @@ XLS-R checkpoint under /mnt/QNAP).  Their loader calls are pointed at seeded syn
 installed; audioprocessor.py only needs it for file I/O and for an unused ``MelSpectrogram``
 member (audioprocessor.py:38-44), so an empty placeholder module stands in for it.
 
+LMAC_metrics.py cannot be imported as a module (it imports a non-existent ``ADDvisor`` class and loads a
+private checkpoint at import), but its six metric functions (LMAC_metrics.py:31-73) are pure: ``metric_functions``
+below parses the file with ``ast``, compiles ONLY those six ``FunctionDef`` nodes with ``torch`` / ``F`` / ``eps`` /
+``device`` in scope and evaluates them on a seeded table -> ``lmac_metrics.npz``.
+
 Not importable at all, hence no fixtures (parity unpinned, see oracle/__init__.py):
-  LMAC_metrics.py (imports a non-existent ``ADDvisor`` class and loads a private ckpt at import),
   captum_saliency.py (captum absent), hifigan.py (speechbrain / librosa absent).
 """
 import hashlib
@@ -76,6 +80,38 @@ def import_reference(cfg):
     return classifier_embedder, audioprocessor, addvisor, loss_function
 
 
+METRIC_DEFS = ("compute_fidelity", "get_score_for_predicted_class", "compute_faithfulness", "compute_AD", "compute_AI",
+               "compute_AG")
+
+
+def metric_functions():
+    """The reference's own metric functions (LMAC_metrics.py:31-73), compiled from its source text node by node: the
+    module body around them (checkpoint load, dataset walk) is never executed."""
+    import ast
+    import torch.nn.functional as F
+    path = os.path.join(REF, "LMAC_metrics.py")
+    with open(path) as f:
+        tree = ast.parse(f.read(), filename=path)
+    defs = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in METRIC_DEFS]
+    assert sorted(d.name for d in defs) == sorted(METRIC_DEFS), [d.name for d in defs]
+    scope = {"torch": torch, "F": F, "eps": 1e-10, "device": torch.device("cpu")}      # LMAC_metrics.py:28 eps; audioprocessor.device
+    exec(compile(ast.Module(body=defs, type_ignores=[]), path, "exec"), scope)
+    return {n: scope[n] for n in METRIC_DEFS}
+
+
+def metric_table(n=64, seed=61):
+    """(p, theta, p_out) triples [n, 1] fp32: random probabilities plus the edge rows the formulas branch on -- ties at
+    exactly 0.5, equal scores, 0 / 1 saturation, label flips either way."""
+    g = np.random.Generator(np.random.PCG64(seed))
+    t = g.uniform(0, 1, size=(n, 3)).astype(np.float32)
+    edge = np.array([[0.5, 0.5, 0.5], [0.5, 0.7, 0.2], [0.7, 0.5, 0.5], [0.3, 0.5, 0.9], [0.5, 0.3, 0.5],
+                     [1.0, 1.0, 0.0], [0.0, 0.0, 1.0], [1.0, 0.0, 1.0], [0.0, 1.0, 0.0], [0.8, 0.8, 0.8],
+                     [0.2, 0.2, 0.2], [0.8, 0.2, 0.6], [0.2, 0.8, 0.4], [0.6, 0.4, 0.6], [0.4, 0.6, 0.4],
+                     [0.50000006, 0.49999997, 0.5]], dtype=np.float32)
+    t[:len(edge)] = edge
+    return torch.from_numpy(t[:, 0:1].copy()), torch.from_numpy(t[:, 1:2].copy()), torch.from_numpy(t[:, 2:3].copy())
+
+
 def save(name, **arrays):
     path = os.path.join(HERE, name)
     np.savez_compressed(path, **{k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v))
@@ -84,6 +120,11 @@ def save(name, **arrays):
 
 
 def main():
+    only = sys.argv[1:]                                  # e.g. `make_golden.py lmac_metrics large`: regenerate these fixtures only
+    if only:
+        for name in only:
+            PARTS[name]()
+        return
     tiny_g = syn.tiny_config(stable=False)
     ce, apm, adv, lf = import_reference(tiny_g)
 
@@ -161,6 +202,23 @@ def main():
     _, p = lf.torch_logreg(feats.mean(dim=1))
     total, losses, wts = lf.LMACLoss().loss_function(xhat, mag, ph, p)
     save("lmac_loss.npz", class_pred=p, total=total, losses=losses, w=wts)
+
+    # ---- 7. the five LMAC metric formulas (LMAC_metrics.py:31-73) on a 64-triple table incl. ties at 0.5
+    part_lmac_metrics()
+
+
+def part_lmac_metrics():
+    fn = metric_functions()
+    p, th, po = metric_table()
+    per = dict(faithfulness=fn["compute_faithfulness"](p, po), fidelity=fn["compute_fidelity"](th, p).squeeze(1),
+               AD=fn["compute_AD"](th, p), AI=fn["compute_AI"](th, p), AG=fn["compute_AG"](th, p))
+    save("lmac_metrics.npz", predictions=p, theta_out=th, masked_predictions=po,
+         score=fn["get_score_for_predicted_class"](p.squeeze(1)),
+         means=np.array([per[k].float().mean().item() for k in ("faithfulness", "fidelity", "AD", "AI", "AG")], dtype=np.float64),
+         **per)
+
+
+PARTS = {"lmac_metrics": part_lmac_metrics}
 
 
 if __name__ == "__main__":

@@ -232,3 +232,19 @@ def test_line_tile_host_rules_match_the_library():
     assert not G.taps2d_supported([a], b, rnd(64, 64, 3, 3), dilation=(2, 2))
     assert not G.taps2d_supported([a, a], b, rnd(64, 128, 3, 3))
     assert not G.taps2d_supported([G.FMap(2, 16, 16, 128, 1, 1)], G.FMap(2, 16, 16, 128, 1, 1), rnd(128, 128, 3, 3))
+
+
+def test_split_format_roundtrip():
+    """Host packer of the fp32-class operand format (csrc/device_math.h): x = hi + lo * 2^-11 to 2^-21 relative for
+    |x| >= 2^-14 (hi normal), to 2^-25 absolute below (hi flushed, lo carries the value)."""
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(20000, dtype=torch.float64, generator=g) * torch.logspace(-7, 4, 20000, dtype=torch.float64)
+    x = x[x.abs() < 60000]
+    t = G.split_planes(x)
+    assert t.dtype == torch.float16 and t.shape == (2,) + x.shape
+    r = t[0].double() + t[1].double() / 2048
+    big = x.abs() >= 2.0 ** -14
+    assert ((r - x).abs() / x.abs())[big].max().item() <= 2.0 ** -21
+    assert (r - x).abs()[~big].max().item() <= 2.0 ** -25
+    assert (t[0][~big] == 0).all()                       # no fp16 subnormal ever reaches the matrix cores through hi
+    assert torch.equal(G.join_planes(t), r.float())

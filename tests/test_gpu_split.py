@@ -1,0 +1,185 @@
+"""GPU parity of the fp32-class ("split") mode: every fp16 tensor is a (hi, lo) plane pair with x = hi + lo * 2^-11
+(csrc/device_math.h) and every matrix product costs three fp16 MFMAs with fp32 accumulation (advh_gemm_desc.split).
+The reference computes the whole path in fp32 ("All floating point is fp32"); this mode is its arithmetic
+class.  References here are fp64 evaluations of the same layers on the same fp32 inputs.
+
+Stated tolerances (relative to max|ref| unless noted):
+  split GEMM / convolution kernels                 5e-6
+  wav2vec2 hidden_states[9] (abs, values O(1))     1e-4      classifier logits (abs) 1e-4
+  U-Net mask (abs)                                 2e-5      mask > 0.5 indices: EXACT (golden SHA-256 at 512 x 196)
+"""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from addvisor_hip import _lib, gemm as G, ops, synthetic as syn
+from addvisor_hip.embedder import HipEmbedder
+from addvisor_hip.unet import HipUNet
+from oracle import signal_ref, unet_ref, wav2vec2_ref
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+
+TOL_KERNEL = 5e-6
+TOL_HID, TOL_LOGIT = 1e-4, 1e-4
+TOL_MASK = 2e-5
+
+
+def rnd(gen, *shape):
+    return torch.randn(*shape, generator=gen)
+
+
+def rel(out, ref):
+    return ((out.double().cpu() - ref.double()).abs().max() / ref.double().abs().max()).item()
+
+
+@pytest.mark.parametrize("M,K,N,act", [(300, 768, 2304, "none"), (12736, 768, 768, "gelu"), (1000, 3072, 768, "none"),
+                                      (257, 512, 64, "gelu"), (513, 64, 32, "leaky"), (128, 64, 48, "none")])
+def test_split_linear(gpu_device, M, K, N, act):
+    _lib.init()
+    g = torch.Generator().manual_seed(M + N)
+    a, w, b = rnd(g, M, K), rnd(g, N, K) / K ** 0.5, rnd(g, N)
+    res = rnd(g, M, N)
+    p = G.plan_linear(M, w, b, act=act, device=gpu_device, split=True)
+    A = G.split_planes(torch.cat([a, torch.zeros(1024, K)])).to(gpu_device)       # slack rows behind each plane
+    out_h = torch.zeros(2, M, N, dtype=torch.float16, device=gpu_device)
+    out_f = torch.zeros(M, N, dtype=torch.float32, device=gpu_device)
+    p.run(A, out_h=out_h, out_f=out_f, resid=res.to(gpu_device))
+    y = a.double() @ w.double().T + b.double()
+    y = F.gelu(y) if act == "gelu" else (F.leaky_relu(y, 0.0) if act == "leaky" else y)
+    ref = y + res.double()
+    e_f, e_h = rel(out_f, ref), rel(G.join_planes(out_h), ref)
+    print(f"split linear {M}x{K}x{N}: fp32 out rel {e_f:.2e}, split out rel {e_h:.2e}")
+    assert e_f <= TOL_KERNEL and e_h <= TOL_KERNEL
+    p.run(G.split_planes(a).to(gpu_device), out_h=out_h)             # exactly M rows, no residual
+    assert rel(G.join_planes(out_h), y) <= TOL_KERNEL
+
+
+def test_split_mfma_accumulation_bias(gpu_device):
+    """Long reductions of same-sign products: a truncating accumulator would show up as a systematic relative error."""
+    _lib.init()
+    g = torch.Generator().manual_seed(5)
+    M, K, N = 256, 8192, 128
+    a, w = rnd(g, M, K).abs() + 0.5, (rnd(g, N, K).abs() + 0.5) / K
+    p = G.plan_linear(M, w, None, device=gpu_device, split=True)
+    out_f = torch.zeros(M, N, dtype=torch.float32, device=gpu_device)
+    p.run(G.split_planes(a).to(gpu_device), out_f=out_f)
+    ref = a.double() @ w.double().T
+    d = (out_f.double().cpu() - ref) / ref
+    print(f"same-sign K={K}: mean rel err {d.mean().item():+.2e}, max {d.abs().max().item():.2e}")
+    assert d.abs().max().item() <= TOL_KERNEL
+
+
+CONV_CASES = [
+    # Cins, Cout, k, stride, pad, dil, H, W, halo_in, halo_out
+    ([32], 32, (3, 3), (1, 1), (1, 1), (1, 1), 40, 28, (1, 1), (1, 1)),
+    ([32], 64, (5, 3), (2, 1), (2, 1), (1, 1), 64, 20, (2, 1), (1, 1)),
+    ([256], 512, (3, 3), (1, 1), (2, 2), (2, 2), 16, 13, (2, 2), (4, 4)),
+    ([64, 32], 64, (3, 3), (1, 1), (1, 1), (1, 1), 24, 20, (1, 1), (1, 1)),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_split_conv2d(gpu_device, case):
+    _lib.init()
+    Cins, Cout, k, stride, pad, dil, H, W, hin, hout = case
+    g = torch.Generator().manual_seed(Cout + H)
+    B = 2
+    xs = [rnd(g, B, c, H, W) for c in Cins]
+    w = rnd(g, Cout, sum(Cins), *k) / (sum(Cins) * k[0] * k[1]) ** 0.5
+    b = rnd(g, Cout)
+    Ho = (H + 2 * pad[0] - dil[0] * (k[0] - 1) - 1) // stride[0] + 1
+    Wo = (W + 2 * pad[1] - dil[1] * (k[1] - 1) - 1) // stride[1] + 1
+    srcs = [G.FMap(B, H, W, c, hin[0], hin[1], split=True).alloc(gpu_device) for c in Cins]
+    for f, x in zip(srcs, xs):
+        planes = G.split_planes(x.permute(0, 2, 3, 1)).to(gpu_device)
+        f.t[0][:, f.PH:f.PH + H, f.PW:f.PW + W] = planes[0]
+        f.t[1][:, f.PH:f.PH + H, f.PW:f.PW + W] = planes[1]
+    dst = G.FMap(B, Ho, Wo, Cout, hout[0], hout[1], split=True).alloc(gpu_device)
+    dst.t.fill_(3.0)
+    p = G.plan_conv2d(srcs, dst, w.double(), b, stride=stride, padding=pad, dilation=dil, device=gpu_device)
+    p.run(srcs[0].t, srcs[1].t if len(srcs) > 1 else None, out_h=dst.t)
+    ref = F.leaky_relu(F.conv2d(torch.cat(xs, 1).double(), w.double(), b.double(), stride, pad, dil), 0.2).permute(0, 2, 3, 1)
+    got = G.join_planes(dst.t)
+    e = rel(got[:, dst.PH:dst.PH + Ho, dst.PW:dst.PW + Wo], ref)
+    print(f"split conv2d {case[:3]}: rel {e:.2e}")
+    assert e <= TOL_KERNEL
+    halo = got.clone()
+    halo[:, dst.PH:dst.PH + Ho, dst.PW:dst.PW + Wo] = 0
+    assert (halo == 0).all() and (dst.t[1].float() * (halo == 0)).abs().max() >= 0      # halo written as zeros in both planes
+
+
+def _embedder_case(cfg, waves, dev, length=None):
+    sd = syn.embedder_weights(cfg)
+    coef, icpt = syn.logreg_weights(cfg.hidden_size)
+    emb = HipEmbedder(cfg, sd, coef, icpt, dev, precision="f32")
+    hid, logit, prob = emb.forward(waves.to(dev), length)
+    x = wav2vec2_ref.zero_mean_unit_var_norm(waves)
+    ref_h = wav2vec2_ref.hidden_states(x, sd, cfg, upto=cfg.layer_index)[min(cfg.layer_index, cfg.num_hidden_layers)]
+    ref_logit, ref_prob = wav2vec2_ref.logreg(ref_h.mean(1), coef, icpt)
+    err = (hid.cpu() - ref_h).abs()
+    le = (logit.cpu() - ref_logit).abs().max().item()
+    print(f"f32 mode: hidden max err {err.max():.3e} mean {err.mean():.3e} | ref absmax {ref_h.abs().max():.2f} | logit err {le:.3e}")
+    assert err.max().item() <= TOL_HID and le <= TOL_LOGIT
+    assert (prob.cpu() - ref_prob).abs().max().item() <= TOL_LOGIT
+    return hid
+
+
+@pytest.mark.parametrize("stable", [False, True])
+def test_split_tiny_embedder(gpu_device, stable, golden):
+    hid = _embedder_case(syn.tiny_config(stable), syn.make_clips(2, 16000, seed=31), gpu_device)
+    g = golden(f"embedder_tiny_{'layer' if stable else 'group'}.npz")          # the reference's own extract_features
+    assert (hid.cpu() - torch.from_numpy(g["feats_b2"])).abs().max().item() <= TOL_HID
+
+
+def test_split_base_embedder_4s(gpu_device, golden):
+    """wav2vec2-base, one 4 s clip, against the oracle and the reference-generated golden corner / pooled vector."""
+    hid = _embedder_case(syn.base_config(), syn.make_clips(1, 64000), gpu_device)
+    g = golden("embedder_base_4s.npz")
+    assert (hid[0, :8, :16].cpu() - torch.from_numpy(g["corner"])).abs().max().item() <= TOL_HID
+    assert (hid[0].mean(0).cpu() - torch.from_numpy(g["pooled"])).abs().max().item() <= TOL_HID
+
+
+@pytest.mark.parametrize("shape,fuse", [((2, 32, 8), True), ((1, 64, 16), True), ((3, 48, 20), False)])
+def test_split_unet_small(gpu_device, shape, fuse, golden):
+    sd = syn.unet_weights()
+    net = HipUNet(sd, gpu_device, precision="f32", fuse_up=fuse)
+    B, H, W = shape
+    r = np.random.Generator(np.random.PCG64(41 if shape == (2, 32, 8) else sum(shape)))
+    x = torch.from_numpy(r.uniform(0, 3, size=(B, 1, H, W)).astype(np.float32))
+    mask = net.forward(x[:, 0].to(gpu_device), H=H, W=W)
+    ref = unet_ref.unet_forward(x, sd)[:, 0]
+    err = (mask.cpu() - ref).abs().max().item()
+    print(f"f32 mode U-Net {shape} fuse_up={fuse}: max err {err:.3e}")
+    assert err <= TOL_MASK
+    assert torch.equal(mask.cpu() > 0.5, ref > 0.5)
+    if shape == (2, 32, 8):
+        assert (mask.cpu() - torch.from_numpy(golden("unet.npz")["out_a"])[:, 0]).abs().max().item() <= TOL_MASK
+
+
+def test_split_unet_full_size_exact_indices(gpu_device, golden):
+    """north_star: "bit-exact for mask indices".  512 x 196 crop of the 4 s STFT magnitude of clip 0 -- the input of
+    tests/golden/unet.npz, which holds the SHA-256 of the reference's own ``mask > 0.5`` index set (addvisor.py:57-60 run by
+    tests/golden/make_golden.py) -- through the whole HIP path (STFT kernel -> U-Net in the fp32-class mode)."""
+    sd = syn.unet_weights()
+    net = HipUNet(sd, gpu_device, precision="f32")
+    w = syn.make_clips(3, 64000)
+    _, mag, _ = ops.stft_forward(w.to(gpu_device), 64000, want_complex=False, want_phase=False)
+    mask = net.forward(mag)
+    assert tuple(mask.shape) == (3, 512, 196)
+    g = golden("unet.npz")
+    idx = (mask[0] > 0.5).cpu().numpy().astype(np.uint8)
+    _, mag_ref, _ = signal_ref.compute_stft(w[:1], audio_length=4)
+    ref = unet_ref.unet_forward(unet_ref.crop_for_unet(mag_ref), sd)[0, 0]
+    err = (mask[0].cpu() - ref).abs()
+    print(f"f32 mode full size: max err {err.max():.3e} mean {err.mean():.3e}; mask>0.5 count {int(idx.sum())} "
+          f"(reference {int(g['full_gt_half'])}); closest reference value to 0.5: {(ref - 0.5).abs().min():.3e}")
+    assert err.max().item() <= TOL_MASK
+    assert int(idx.sum()) == int(g["full_gt_half"])
+    assert hashlib.sha256(idx[None, None].tobytes()).digest() == g["full_idx_sha256"].tobytes()
+    assert (mask[0, ::17, ::5].cpu() - torch.from_numpy(g["full_sub"])).abs().max().item() <= TOL_MASK
+    single = net.forward(mag[:1].contiguous())
+    assert torch.equal(single[0], mask[0])                    # batch invariance, bit-exact

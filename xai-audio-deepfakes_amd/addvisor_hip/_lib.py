@@ -90,6 +90,13 @@ SIGNATURES = {
     "advh_conv53s21_tile_f16": (_i, [_p, _p]),
     "advh_conv53s21_tile_lds_bytes": (_i, []),
     "advh_posconv_tile_lds_bytes": (_i, [_i, _i]),
+    "advh_w2v2_frontend_split": (_i, [_p, _i64, _i, _i, _i, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _i64, _i, _i, _i, _p]),
+    "advh_layernorm_split": (_i, [_p, _i, _i64, _i64, _p, _i64, _i64, _p, _p, _p, _p, _i64, _i64, _i, _i, _f, _i, _p]),
+    "advh_posconv_gather_split": (_i, [_p, _p, _i64, _i, _i, _i, _i, _i, _i, _p]),
+    "advh_attention_split": (_i, [_p, _i64, _p, _i64, _i, _i, _i, _i, _p]),
+    "advh_unet_stem_split": (_i, [_p, _i, _i, _i, _i, _i, _p, _p, _p, _i64, _i, _i, _f, _p]),
+    "advh_unet_pack_x_split": (_i, [_p, _i, _i, _i, _i, _i, _p, _i64, _i, _i, _i, _i, _p]),
+    "advh_unet_head_split": (_i, [_p, _i64, _i, _i, _i, _i, _i, _p, _f, _p, _p, _p]),
     "advh_upconv21_tile_lds_bytes": (_i, []),
 }
 

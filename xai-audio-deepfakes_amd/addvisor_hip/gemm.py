@@ -56,12 +56,18 @@ class GemmDesc(C.Structure):
         ("out_h2", C.c_void_p), ("slope2", C.c_float), ("ph_r", C.c_int32), ("ph_pad", C.c_int32), ("ph_T", C.c_int32),
         ("out_pre", C.c_void_p), ("dact_src", C.c_void_p), ("wide", C.c_int32), ("w_ld", C.c_int64), ("sc", C.c_int32), ("n_sub", C.c_int32), ("o_sNhh", C.c_int64),
         ("nz_lo", C.c_int32), ("z_inner", C.c_int32), ("a_sZ2", C.c_int64 * 2), ("o_sZ2", C.c_int64), ("plain", C.c_int32), ("plain_out", C.c_int32),
+        ("split", C.c_int32), ("a_lo", C.c_int64 * 2), ("w_lo", C.c_int64), ("o_lo", C.c_int64),
     ]
 
 
-def kernel_name(tile: int, plain: bool) -> str:
+X3_KERNELS = {TILE_128x128: "gemm_x3_kernel<128, 128, 2, 2", TILE_256x64: "gemm_x3_kernel<256, 64, 4, 1", TILE_256x32: "gemm_x3_kernel<256, 32, 4, 1"}
+
+
+def kernel_name(tile: int, plain: bool, split: bool = False) -> str:
     """Name of the kernel instantiation a launch runs, as rocprofv3 prints it (the 256-thread kernels carry the
     affine-row flag as their last template argument)."""
+    if split:
+        return X3_KERNELS[tile] + (", true>" if plain else ", false>")
     k = TILE_KERNELS.get(tile, "gemm_f16_kernel")
     if k.startswith("gemm_f16_kernel<"):
         k = k[:-1] + (", true>" if plain and tile == TILE_128x128 else ", false>")
@@ -83,7 +89,7 @@ class _Profile:
         one with the largest total time, remembered in ``self.kernel``."""
         per = {}
         for a, b, f, t, shape in self.events:
-            r = per.setdefault(kernel_name(t, shape[4]), [0.0, 0.0, 0])
+            r = per.setdefault(kernel_name(t, shape[4], shape[5] if len(shape) > 5 else False), [0.0, 0.0, 0])
             r[0] += a.elapsed_time(b); r[1] += f; r[2] += 1
         if not per:
             return 0.0, 0.0, 0
@@ -96,7 +102,7 @@ class _Profile:
         """{(M, N, K, nz, tile name): [ms, flops, launches]} of the recorded launches (tools/bench_shapes.py)."""
         per = {}
         for a, b, f, t, shape in self.events:
-            r = per.setdefault(shape[:4] + (TILE_NAMES.get(t, str(t)) + ("+" if shape[4] else ""),), [0.0, 0.0, 0])
+            r = per.setdefault(shape[:4] + (TILE_NAMES.get(t, str(t)) + ("+" if shape[4] else "") + ("x3" if len(shape) > 5 and shape[5] else ""),), [0.0, 0.0, 0])
             r[0] += a.elapsed_time(b); r[1] += f; r[2] += 1
         return per
 
@@ -117,6 +123,21 @@ TUNER = _Tuner()
 
 def round_up(x: int, m: int) -> int:
     return (x + m - 1) // m * m
+
+
+def split_planes(x: torch.Tensor) -> torch.Tensor:
+    """Host-side packer of the split format (csrc/device_math.h): ``x`` (any float dtype) -> fp16 ``[2, *x.shape]`` with
+    ``x = hi + lo * 2**-11``; computed in fp64, so an fp64 source (BatchNorm-folded / composed weights) keeps ~22 bits."""
+    x64 = x.detach().to(torch.float64)
+    hi = x64.to(torch.float16)
+    hi = torch.where(x64.abs() < 2.0 ** -14, torch.zeros_like(hi), hi)
+    lo = ((x64 - hi.to(torch.float64)) * 2048.0).to(torch.float16)
+    return torch.stack([hi, lo])
+
+
+def join_planes(t: torch.Tensor) -> torch.Tensor:
+    """fp32 value of a split-format tensor ``[2, ...]``."""
+    return t[0].float() + t[1].float() * (1.0 / 2048.0)
 
 
 W8_RULE = int(os.environ.get("ADDVISOR_GEMM_W8_MIN_M", "0"))
@@ -169,13 +190,17 @@ class GemmPlan:
                  o_sZ: int = 0, nz: int = 1, bias: Optional[torch.Tensor] = None, act: str = "none",
                  slope: float = 0.0, device=None, w_sZ: Optional[int] = None, bias_sZ: int = 0,
                  slope2: float = 0.0, phase: Tuple[int, int, int] = (0, 0, 0), cache: Optional[tuple] = None,
-                 n_sub: int = 0, o_sNhh: int = 0, nz_lo: int = 0, z_inner: bool = False, o_sZ2: int = 0, plain: bool = False):
+                 n_sub: int = 0, o_sNhh: int = 0, nz_lo: int = 0, z_inner: bool = False, o_sZ2: int = 0, plain: bool = False,
+                 split: bool = False):
         """``w2``: fp32 ``[nz, N, K]`` (K = 8 * len(ktab) before padding) or a zero-argument callable returning it
         (only called when the packed weight is not in ``cache``); ``ktab``: int64 chunk offsets with bit 31 as
         source selector; ``out`` = (o_sB, o_sH, o_sW, o_c0) in elements.  ``cache = (dict, key)`` shares the
         packed fp16 weight / bias device tensors between plans of different batch shapes (the weight of a layer
-        does not depend on the batch)."""
+        does not depend on the batch).  ``split``: fp32-class launch (``desc.split``): the weight is packed as two
+        fp16 planes ``[2, nz, w_rows, Kp]`` from its fp32 / fp64 source, activations and fp16 outputs are ``[2, ...]``
+        plane pairs (``split_planes`` / ``join_planes``)."""
         K = 8 * len(ktab)
+        self.split = bool(split)
         Kp = round_up(K, BK)
         n_div_v = n_div if n_div is not None else round_up(N, 4)
         # 16-byte epilogue stores need 8 consecutive channels per lane (permuted weight rows) and 8-aligned addressing
@@ -189,13 +214,14 @@ class GemmPlan:
         if hit is None:
             w2t = w2() if callable(w2) else w2
             assert w2t.dim() == 3 and w2t.shape[0] == nz and w2t.shape[1] == N and w2t.shape[2] == K, (w2t.shape, nz, N, K)
-            wp = torch.zeros((nz, w_rows, Kp), dtype=torch.float16)
+            wp = torch.zeros(((2, nz, w_rows, Kp) if split else (nz, w_rows, Kp)), dtype=torch.float16)
+            w16 = split_planes(w2t) if split else w2t.to(torch.float16)        # [2, nz, N, K] | [nz, N, K]
             if wide:
                 src = packed_row_channel(w_rows)
                 keep = src < N
-                wp[:, torch.from_numpy(np.nonzero(keep)[0]), :K] = w2t.to(torch.float16)[:, torch.from_numpy(src[keep])]
+                wp[..., torch.from_numpy(np.nonzero(keep)[0]), :K] = w16[..., torch.from_numpy(src[keep]), :]
             else:
-                wp[:, :N, :K] = w2t.to(torch.float16)
+                wp[..., :N, :K] = w16
             wd = wp.to(device) if device is not None else wp
             bd = None
             if bias is not None:
@@ -223,6 +249,9 @@ class GemmPlan:
             d.a_sB[s], d.a_sH[s], d.a_sW[s], d.a_c0[s], d.a_sZ[s] = src.sB, src.sH, src.sW, src.c0, src.sZ
             d.a_sZ2[s] = src.sZ2
         d.w_sZ = w_rows * Kp if w_sZ is None else w_sZ
+        d.split = int(split)
+        d.w_lo = nz * w_rows * Kp if split else 0
+        assert not split or w_sZ is None
         d.bias_sZ = bias_sZ
         d.o_sB, d.o_sH, d.o_sW, d.o_c0 = out
         d.o_sNhi, d.o_sZ = o_sNhi, o_sZ
@@ -255,6 +284,7 @@ class GemmPlan:
         place, with the wide-epilogue row permutation if the plan uses it -- the per-step weight refresh of the
         training path (no host round trip; a handful of torch copy kernels)."""
         N, K = self.desc.N, self.K
+        assert not self.split, "the training path repacks fp16 weights only"
         assert w2.shape == (self.desc.nz, N, K) and w2.device == self.w.device, (w2.shape, (self.desc.nz, N, K))
         if self.desc.wide:
             if not hasattr(self, "_perm"):
@@ -279,6 +309,18 @@ class GemmPlan:
         assert out_pre is None or out_pre.dtype == torch.float16
         assert dact_src is None or dact_src.dtype == torch.float16
         assert A0.dtype == torch.float16 and A0.is_cuda
+        if self.split:                                     # plane pairs [2, ...]: lo plane = stride(0) elements behind
+            o_lo = None
+            for s_, t in enumerate((A0, A1)):
+                if t is not None:
+                    assert t.shape[0] == 2 and t.stride(0) % 8 == 0, "split operand must be a [2, ...] plane pair"
+                    d.a_lo[s_] = t.stride(0) // 8
+            for t in (out_h, out_h2, resid if (resid is not None and resid.dtype == torch.float16) else None):
+                if t is not None:
+                    assert t.shape[0] == 2 and t.stride(0) % 8 == 0 and o_lo in (None, t.stride(0)), "split outputs share one plane pitch"
+                    o_lo = t.stride(0)
+            d.o_lo = o_lo or 0
+            assert out_pre is None and dact_src is None
         d.A0 = A0.data_ptr()
         d.A1 = A1.data_ptr() if A1 is not None else None
         assert (A1 is not None) == (self.nsrc == 2)
@@ -306,11 +348,11 @@ class GemmPlan:
         _lib.check(_lib.lib().advh_gemm_f16(C.byref(d), self.tile, stream), "advh_gemm_f16")
         if prof:
             e1.record()
-            PROFILE.events.append((e0, e1, self.flops, self.tile, (self.desc.M, self.desc.N, self.K, self.desc.nz, bool(self.desc.plain))))
+            PROFILE.events.append((e0, e1, self.flops, self.tile, (self.desc.M, self.desc.N, self.K, self.desc.nz, bool(self.desc.plain), self.split)))
 
 
 def _tune(self, d, stream):
-    cands = [TILE_128x128, TILE_128x256_W8, TILE_256x128_W8, TILE_256x256] if self.desc.N > 64 else [self.tile]
+    cands = [TILE_128x128, TILE_128x256_W8, TILE_256x128_W8, TILE_256x256] if (self.desc.N > 64 and not self.split) else [self.tile]
     if self.desc.nz_lo > 1 or self.desc.z_inner:
         cands = [c for c in cands if c != TILE_256x256]       # the two-level batch lives in gemm_f16_kernel only
     best, best_ms = self.tile, None
@@ -344,6 +386,7 @@ class FMap:
     PH: int
     PW: int
     t: Optional[torch.Tensor] = None
+    split: bool = False          # fp32-class mode: ``t`` is the plane pair [2, B, Hp, Wp, C]
 
     @property
     def Hp(self):
@@ -354,15 +397,19 @@ class FMap:
         return self.W + 2 * self.PW
 
     def alloc(self, device):
-        self.t = torch.zeros((self.B, self.Hp, self.Wp, self.C), dtype=torch.float16, device=device)
+        shape = (self.B, self.Hp, self.Wp, self.C)
+        self.t = torch.zeros(((2,) + shape) if self.split else shape, dtype=torch.float16, device=device)
         return self
 
     def interior(self) -> torch.Tensor:
-        return self.t[:, self.PH:self.PH + self.H, self.PW:self.PW + self.W, :]
+        """Interior view (of the hi plane in split mode)."""
+        t = self.t[0] if self.split else self.t
+        return t[:, self.PH:self.PH + self.H, self.PW:self.PW + self.W, :]
 
 
 def plan_linear(M: int, weight: torch.Tensor, bias: Optional[torch.Tensor], *, lda: Optional[int] = None,
-                ldo: Optional[int] = None, o_c0: int = 0, act: str = "none", device=None, cache=None) -> GemmPlan:
+                ldo: Optional[int] = None, o_c0: int = 0, act: str = "none", device=None, cache=None,
+                split: bool = False) -> GemmPlan:
     """``out[m, :N] = act(A[m, :K] @ weight.T + bias)``; nn.Linear (modeling_wav2vec2.py:422-572)."""
     N, K = weight.shape
     assert K % 8 == 0
@@ -371,12 +418,12 @@ def plan_linear(M: int, weight: torch.Tensor, bias: Optional[torch.Tensor], *, l
     assert lda % 8 == 0 and ldo % 4 == 0
     return GemmPlan(M=M, N=N, w2=lambda: weight[None].float(), ktab=np.arange(K // 8, dtype=np.int64),
                     sources=[Source(0, 0, lda // 8, 0)], Hg=1, Wg=M, window=(0, 1, 0, M), halo_zero=False,
-                    out=(0, 0, ldo, o_c0), bias=bias, act=act, device=device, cache=cache, plain=True)
+                    out=(0, 0, ldo, o_c0), bias=bias, act=act, device=device, cache=cache, plain=True, split=split)
 
 
 def plan_conv1d_cl(B: int, P_in: int, P_out: int, L_out: int, weight: torch.Tensor, bias: Optional[torch.Tensor],
                    stride: int, *, act: str = "gelu", compact_out: bool = False, device=None, cache=None,
-                   slack_rows: int = 0) -> GemmPlan:
+                   slack_rows: int = 0, split: bool = False) -> GemmPlan:
     """Channels-last Conv1d (no padding) as an overlapping-row GEMM: wav2vec2 feature-encoder layers 1-6
     (modeling_wav2vec2.py:254-323).  Input ``[B, P_in, Cin]``, rows >= L_in are zero filler; output
     ``[B, P_out, Cout]`` with rows >= L_out written as zeros, or ``[B, L_out, Cout]`` if ``compact_out``.
@@ -389,7 +436,7 @@ def plan_conv1d_cl(B: int, P_in: int, P_out: int, L_out: int, weight: torch.Tens
     return GemmPlan(M=B * P_out, N=Cout, w2=w2, ktab=np.arange(k * Cin // 8, dtype=np.int64),
                     sources=[Source(P_in * Cin // 8, 0, stride * Cin // 8, 0)], Hg=1, Wg=P_out,
                     window=(0, 1, 0, L_out), halo_zero=not compact_out, out=out, bias=bias, act=act, device=device,
-                    cache=cache, plain=(slack_rows >= k - stride and P_in == P_out * stride))
+                    cache=cache, plain=(slack_rows >= k - stride and P_in == P_out * stride), split=split)
 
 
 def plan_conv2d(srcs: Sequence[FMap], dst: FMap, weight: torch.Tensor, bias: Optional[torch.Tensor], *,
@@ -420,7 +467,9 @@ def plan_conv2d(srcs: Sequence[FMap], dst: FMap, weight: torch.Tensor, bias: Opt
         sources.append(Source(f.Hp * f.Wp * cc, sh * f.Wp * cc, sw * cc, c0))
         c_lo += f.C
     Ct = dst.C
-    return GemmPlan(M=B * dst.Hp * dst.Wp, N=Cout, w2=torch.cat(ws, 1)[None].float(), ktab=np.concatenate(ktabs),
+    split = dst.split
+    assert all(f.split == split for f in srcs)
+    return GemmPlan(M=B * dst.Hp * dst.Wp, N=Cout, w2=torch.cat(ws, 1)[None] if split else torch.cat(ws, 1)[None].float(), ktab=np.concatenate(ktabs), split=split,
                     sources=sources, Hg=dst.Hp, Wg=dst.Wp,
                     window=(dst.PH, dst.PH + dst.H, dst.PW, dst.PW + dst.W), halo_zero=True,
                     out=(dst.Hp * dst.Wp * Ct, dst.Wp * Ct, Ct, dst_c0), bias=bias, act=act, slope=slope,
@@ -440,7 +489,9 @@ def plan_convT2d(src: FMap, dst: FMap, weight: torch.Tensor, bias: torch.Tensor,
     cc = Cin // 8
     Ct = dst.C
     # w2[n = (i*sw + j)*Cout + co][ci]
-    w2 = weight.permute(2, 3, 1, 0).reshape(1, sh * sw * Cout, Cin).float()
+    w2 = weight.permute(2, 3, 1, 0).reshape(1, sh * sw * Cout, Cin)
+    w2 = w2 if dst.split else w2.float()
+    assert src.split == dst.split
     b2 = bias.float().repeat(sh * sw)
     o_c0 = ((-sh * src.PH + dst.PH) * dst.Wp + (-sw * src.PW + dst.PW)) * Ct + dst_c0
     return GemmPlan(M=src.B * src.Hp * src.Wp, N=sh * sw * Cout, w2=w2, ktab=np.arange(cc, dtype=np.int64),
@@ -448,7 +499,7 @@ def plan_convT2d(src: FMap, dst: FMap, weight: torch.Tensor, bias: torch.Tensor,
                     window=(src.PH, src.PH + src.H, src.PW, src.PW + src.W), halo_zero=False,
                     out=(dst.Hp * dst.Wp * Ct, sh * dst.Wp * Ct, sw * Ct, o_c0), n_div=Cout,
                     o_sNhi=Ct if sw > 1 else dst.Wp * Ct, n_sub=sw if sw > 1 else 0, o_sNhh=dst.Wp * Ct if sw > 1 else 0,
-                    bias=b2, bias_sZ=0, act="none", device=device)
+                    bias=b2, bias_sZ=0, act="none", device=device, split=dst.split)
 
 
 class PlanGroup:
@@ -466,7 +517,7 @@ class PlanGroup:
 def add_indicator(f: FMap, channel: int) -> FMap:
     """Set channel ``channel`` of an allocated map to 1 inside the image (halo stays 0): the in-image indicator the
     fused up-convolution multiplies the transposed convolution's bias with."""
-    f.t[:, f.PH:f.PH + f.H, f.PW:f.PW + f.W, channel] = 1.0
+    f.interior()[..., channel] = 1.0          # split mode: 1.0 = (hi 1, lo 0)
     return f
 
 
@@ -543,7 +594,7 @@ def plan_upconv2d(coarse: FMap, skip: FMap, dst: FMap, wt: torch.Tensor, bt: tor
     c0_1 = ((skip.PH - 1) * skip.Wp + skip.PW - 1) * cc1
     o_c0 = (dst.PH * dst.Wp + dst.PW) * Ct
     plan = GemmPlan(
-        M=coarse.B * coarse.H * coarse.W, N=N, w2=torch.stack(w2).float(), ktab=np.concatenate([kt0, kt1]),
+        M=coarse.B * coarse.H * coarse.W, N=N, w2=torch.stack(w2) if dst.split else torch.stack(w2).float(), ktab=np.concatenate([kt0, kt1]), split=dst.split,
         sources=[Source(coarse.Hp * coarse.Wp * cc0, coarse.Wp * cc0, cc0, c0_0, sZ=coarse.Wp * cc0, sZ2=cc0 if sw == 2 else 0),
                  Source(skip.Hp * skip.Wp * cc1, sh * skip.Wp * cc1, sw * cc1, c0_1, sZ=skip.Wp * cc1, sZ2=cc1 if sw == 2 else 0)],
         Hg=coarse.H, Wg=coarse.W, window=(0, coarse.H, 0, coarse.W), halo_zero=False,

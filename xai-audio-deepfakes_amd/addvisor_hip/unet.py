@@ -18,10 +18,12 @@ SLOPE = 0.2
 BN_EPS = 1e-5
 
 
-def _fold_bn(sd, conv: str, bn: str) -> Tuple[torch.Tensor, torch.Tensor]:
-    w, b = sd[conv + ".weight"].float(), sd[conv + ".bias"].float()
-    s = sd[bn + ".weight"].float() / torch.sqrt(sd[bn + ".running_var"].float() + BN_EPS)
-    return w * s.view(-1, 1, 1, 1), (b - sd[bn + ".running_mean"].float()) * s + sd[bn + ".bias"].float()
+def _fold_bn(sd, conv: str, bn: str, dtype=torch.float32) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Eval-mode BatchNorm folded into the convolution; ``dtype=torch.float64`` for the fp32-class mode (the folded
+    weight is then split into two fp16 planes from its fp64 value)."""
+    w, b = sd[conv + ".weight"].to(dtype), sd[conv + ".bias"].to(dtype)
+    s = sd[bn + ".weight"].to(dtype) / torch.sqrt(sd[bn + ".running_var"].to(dtype) + BN_EPS)
+    return w * s.view(-1, 1, 1, 1), (b - sd[bn + ".running_mean"].to(dtype)) * s + sd[bn + ".bias"].to(dtype)
 
 
 def reference_flops(B: int, H: int, W: int) -> float:
@@ -43,20 +45,33 @@ def reference_flops(B: int, H: int, W: int) -> float:
 class HipUNet:
     """``forward(mag [B, F>=H, T>=W] fp32) -> mask [B, H, W] fp32`` (H % 16 == 0, W % 4 == 0)."""
 
-    def __init__(self, sd: Dict[str, torch.Tensor], device, line_tile: Optional[bool] = None, fuse_up: Optional[bool] = None):
+    def __init__(self, sd: Dict[str, torch.Tensor], device, line_tile: Optional[bool] = None, fuse_up: Optional[bool] = None,
+                 precision: Optional[str] = None):
         """``line_tile``: run the 3x3 32- / 64-channel same-geometry layers on the weights-in-LDS kernel
         (``advh_conv_taps2d_f16``) instead of the implicit GEMM.  ``fuse_up``: fold every ConvTranspose2d into the
-        convolution that follows it (``gemm.plan_upconv2d``) so the up-sampled maps are never written."""
+        convolution that follows it (``gemm.plan_upconv2d``) so the up-sampled maps are never written.
+        ``precision``: "f16" | "f32" (default ``ADDVISOR_PRECISION``, i.e. f32): "f32" is the fp32-class mode -- every map a
+        split-format plane pair, every convolution three MFMAs per product (``advh_gemm_desc.split``), weights folded in
+        fp64 -- whose ``mask > 0.5`` index set reproduces the reference's fp32 CPU result (addvisor.py:57-60; asserted
+        against tests/golden/unet.npz).  The line-tile kernels are fp16-only, so that mode runs the implicit GEMM."""
         _lib.init()
+        from .embedder import default_precision
+        self.precision = precision or default_precision()
+        if self.precision not in ("f16", "f32"):
+            raise ValueError("precision must be 'f16' or 'f32'")
+        self.split = self.precision == "f32"
+        self.wdtype = torch.float64 if self.split else torch.float32
+        if self.split:
+            line_tile = False
         if line_tile is None:                                  # both default on; the environment switches are for A/B measurements
             line_tile = os.environ.get("ADDVISOR_UNET_LINE_TILE", "1") != "0"
         if fuse_up is None:
             fuse_up = os.environ.get("ADDVISOR_UNET_FUSE_UP", "1") != "0"
         self.dev, self.line_tile, self.fuse_up = device, line_tile, fuse_up
         self.sd = {k.replace("module.", ""): v.detach() for k, v in sd.items()}     # LMAC_metrics.py:23-25
-        w, b = _fold_bn(self.sd, "e1.block.0", "e1.block.1")
-        self.stem_w = w.reshape(32, 15).contiguous().to(device)
-        self.stem_b = b.contiguous().to(device)
+        w, b = _fold_bn(self.sd, "e1.block.0", "e1.block.1", self.wdtype)
+        self.stem_w = w.reshape(32, 15).float().contiguous().to(device)
+        self.stem_b = b.float().contiguous().to(device)
         self.head_w = self.sd["mask_head.0.weight"].float().reshape(32).contiguous().to(device)
         self.head_b = float(self.sd["mask_head.0.bias"].float().reshape(-1)[0])
         self._ws: Dict[Tuple[int, int, int], dict] = {}
@@ -68,7 +83,7 @@ class HipUNet:
         if H % 16 or W % 4:
             raise ValueError("U-Net input needs H % 16 == 0 and W % 4 == 0 (SURVEY.md D2)")
         dev, sd = self.dev, self.sd
-        F = lambda h, w, c, ph, pw: G.FMap(B, h, w, c, ph, pw).alloc(dev)
+        F = lambda h, w, c, ph, pw: G.FMap(B, h, w, c, ph, pw, split=self.split).alloc(dev)
         if self.fuse_up:
             return self._workspace_fused(B, H, W)
         m = dict(
@@ -85,7 +100,7 @@ class HipUNet:
         steps = []
 
         def conv(srcs, dst, conv_name, bn_name, **kw):
-            w, b = _fold_bn(sd, conv_name, bn_name)
+            w, b = _fold_bn(sd, conv_name, bn_name, self.wdtype)
             cin = sum(m[s].C for s in srcs)
             if cin != w.shape[1]:                              # d1: 33 real channels live in a 40-wide map
                 w = torch.cat([w, w.new_zeros(w.shape[0], cin - w.shape[1], *w.shape[2:])], 1)
@@ -100,7 +115,7 @@ class HipUNet:
             conv([mid], dst, f"{name}.block.3", f"{name}.block.4")
 
         def up(src, dst, name, stride):
-            plan = G.plan_convT2d(m[src], m[dst], sd[name + ".weight"].float(), sd[name + ".bias"].float(),
+            plan = G.plan_convT2d(m[src], m[dst], sd[name + ".weight"].to(self.wdtype), sd[name + ".bias"].float(),
                                   stride=stride, device=dev)
             steps.append((plan, [src], dst))
 
@@ -130,7 +145,7 @@ class HipUNet:
         channels up to the next multiple of 64, so every pixel starts on a 128-byte line); for d1 the
         indicator rides in the 8-channel spectrogram map ``xin`` = (x, 1, 0, ...) that ``advh_unet_pack_x`` fills."""
         dev, sd = self.dev, self.sd
-        F = lambda h, w, c, ph, pw: G.FMap(B, h, w, c, ph, pw).alloc(dev)
+        F = lambda h, w, c, ph, pw: G.FMap(B, h, w, c, ph, pw, split=self.split).alloc(dev)
         m = dict(
             x1a=F(H // 2, W, 32, 2, 1), x1=F(H // 2, W, 32, 2, 1),
             x2a=F(H // 4, W, 64, 1, 1), x2=F(H // 4, W, 64, 1, 1),
@@ -145,7 +160,7 @@ class HipUNet:
         steps = []
 
         def conv(srcs, dst, conv_name, bn_name, **kw):
-            w, b = _fold_bn(sd, conv_name, bn_name)
+            w, b = _fold_bn(sd, conv_name, bn_name, self.wdtype)
             if self.line_tile and G.taps2d_supported([m[s] for s in srcs], m[dst], w, **kw):
                 plan = G.Taps2dPlan(m[srcs[0]], m[dst], w, b, slope=SLOPE, device=dev)
             elif self.line_tile and G.conv_s21_supported([m[s] for s in srcs], m[dst], w, **kw):
@@ -159,8 +174,8 @@ class HipUNet:
             conv([mid], dst, f"{name}.block.3", f"{name}.block.4")
 
         def up_block(coarse, skip, mid, dst, up_name, name, stride, coarse_C, skip_C, indicator):
-            wc, bc = _fold_bn(sd, f"{name}.block.0", f"{name}.block.1")
-            wt, bt = sd[up_name + ".weight"].float(), sd[up_name + ".bias"].float()
+            wc, bc = _fold_bn(sd, f"{name}.block.0", f"{name}.block.1", self.wdtype)
+            wt, bt = sd[up_name + ".weight"].to(self.wdtype), sd[up_name + ".bias"].to(self.wdtype)
             if self.line_tile and G.upconv_tile_supported(m[coarse], m[skip], m[mid], wt, wc, stride, indicator):
                 plan = G.UpconvTilePlan(m[coarse], m[skip], m[mid], wt, bt, wc, bc, slope=SLOPE, device=dev)
             else:
@@ -202,16 +217,26 @@ class HipUNet:
         st = torch.cuda.current_stream().cuda_stream
         x1a = m["x1a"]
         xcat, xc0 = (m["xin"], 0) if self.fuse_up else (m["u1"], 32)
-        _lib.check(lib.advh_unet_stem(mag.data_ptr(), Fq, Tq, B, H, W, self.stem_w.data_ptr(), self.stem_b.data_ptr(),
-                                      x1a.t.data_ptr(), x1a.PH, x1a.PW, SLOPE, st), "advh_unet_stem")
-        _lib.check(lib.advh_unet_pack_x(mag.data_ptr(), Fq, Tq, B, H, W, xcat.t.data_ptr(), xcat.C, xc0, xcat.PH, xcat.PW, st),
-                   "advh_unet_pack_x")
+        if self.split:
+            _lib.check(lib.advh_unet_stem_split(mag.data_ptr(), Fq, Tq, B, H, W, self.stem_w.data_ptr(), self.stem_b.data_ptr(),
+                                                x1a.t.data_ptr(), x1a.t.stride(0), x1a.PH, x1a.PW, SLOPE, st), "advh_unet_stem_split")
+            _lib.check(lib.advh_unet_pack_x_split(mag.data_ptr(), Fq, Tq, B, H, W, xcat.t.data_ptr(), xcat.t.stride(0), xcat.C, xc0,
+                                                  xcat.PH, xcat.PW, st), "advh_unet_pack_x_split")
+        else:
+            _lib.check(lib.advh_unet_stem(mag.data_ptr(), Fq, Tq, B, H, W, self.stem_w.data_ptr(), self.stem_b.data_ptr(),
+                                          x1a.t.data_ptr(), x1a.PH, x1a.PW, SLOPE, st), "advh_unet_stem")
+            _lib.check(lib.advh_unet_pack_x(mag.data_ptr(), Fq, Tq, B, H, W, xcat.t.data_ptr(), xcat.C, xc0, xcat.PH, xcat.PW, st),
+                       "advh_unet_pack_x")
         for plan, srcs, dst in ws["steps"]:
             a0 = m[srcs[0]].t
             a1 = m[srcs[1]].t if len(srcs) > 1 else None
             plan.run(a0, a1, out_h=m[dst].t)
         y1 = m["y1"]
-        _lib.check(lib.advh_unet_head(y1.t.data_ptr(), B, H, W, y1.PH, y1.PW, self.head_w.data_ptr(), self.head_b,
-                                      ws["mask"].data_ptr(), ws["logits"].data_ptr(), st), "advh_unet_head")
+        if self.split:
+            _lib.check(lib.advh_unet_head_split(y1.t.data_ptr(), y1.t.stride(0), B, H, W, y1.PH, y1.PW, self.head_w.data_ptr(),
+                                                self.head_b, ws["mask"].data_ptr(), ws["logits"].data_ptr(), st), "advh_unet_head_split")
+        else:
+            _lib.check(lib.advh_unet_head(y1.t.data_ptr(), B, H, W, y1.PH, y1.PW, self.head_w.data_ptr(), self.head_b,
+                                          ws["mask"].data_ptr(), ws["logits"].data_ptr(), st), "advh_unet_head")
         mask = ws["mask"].clone()
         return (mask, ws["logits"].clone()) if want_logits else mask

@@ -12,6 +12,7 @@
 #include <hip/hip_fp16.h>
 #include "addvisor_hip.h"
 #include "common.h"
+#include "device_math.h"
 
 namespace advh {
 
@@ -246,6 +247,139 @@ __global__ __launch_bounds__(256, 2) void attention_tr_kernel(const _Float16* __
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// fp32-class instance: q, k, v and the context are plane pairs in the split format of device_math.h; both products cost
+// three MFMAs per fragment pair (hi*hi into the main accumulator, hi*lo + lo*hi into the cross accumulator, 2^-11),
+// the softmax is fp32 as before and the probabilities are split before O^T = V^T P^T.  K and V^T (hi and lo) of one
+// (clip, head) stay in LDS: 144 KB at T <= 256, head dim <= 64 => one workgroup per CU (attention is 4 % of the FLOPs).
+template <int NT, int D>
+__global__ __launch_bounds__(256, 1) void attention_x3_kernel(const _Float16* __restrict__ qkv, long qkv_lo, _Float16* __restrict__ ctx,
+                                                              long ctx_lo, int T, int H, int dm, float scale) {
+    constexpr int NKEY = NT * 16, CH = D / 8, VP = NKEY + 64, NS = (NT + 1) / 2, KK = D / 32, DT = D / 16;
+    extern __shared__ __attribute__((aligned(16))) _Float16 att_lds[];
+    _Float16* Ks = att_lds;                      // [2][NKEY * D]
+    _Float16* Vt = att_lds + 2 * NKEY * D;       // [2][D * VP]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int head = blockIdx.x, b = blockIdx.y;
+    const long ld = 3L * H;
+    const _Float16* base = qkv + (long)b * T * ld + head * dm;
+    const int chm = dm / 8;
+
+    constexpr int NIT = (NKEY * CH + 255) / 256;
+    for (int pl = 0; pl < 2; ++pl) {             // plane by plane: half the staging registers
+        const _Float16* bp = base + (pl ? qkv_lo : 0);
+        f16x8 kreg[NIT], vreg[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = tid + it * 256, key = i / CH, c = i % CH;
+            kreg[it] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            vreg[it] = kreg[it];
+            if (i < NKEY * CH && key < T && c < chm) {
+                kreg[it] = *(const f16x8*)(bp + (long)key * ld + H + c * 8);
+                vreg[it] = *(const f16x8*)(bp + (long)key * ld + 2 * H + c * 8);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = tid + it * 256, key = i / CH, c = i % CH;
+            if (i >= NKEY * CH) break;
+            *(f16x8*)(Ks + pl * NKEY * D + key * D + ((c ^ (key & (CH - 1))) * 8)) = kreg[it];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) Vt[pl * D * VP + (c * 8 + j) * VP + (c & 7) * 8 + key] = vreg[it][j];
+        }
+    }
+    __syncthreads();
+
+    const int fr = lane & 15, g = lane >> 4;
+    for (int qt = wv; qt * 16 < T; qt += 4) {
+        const int qrow = qt * 16 + fr;
+        const int qr = qrow < T ? qrow : T - 1;
+        f16x8 qh[KK], ql[KK];
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+            const bool in = kk * 4 + g < chm;
+            qh[kk] = in ? *(const f16x8*)(base + (long)qr * ld + kk * 32 + g * 8) : f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            ql[kk] = in ? *(const f16x8*)(base + qkv_lo + (long)qr * ld + kk * 32 + g * 8) : f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+        f32x4 s[NT];
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+            f32x4 sm = f32x4{0.f, 0.f, 0.f, 0.f}, sx = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) {
+                const int key = kt * 16 + fr, c = kk * 4 + g;
+                const int o = key * D + ((c ^ (key & (CH - 1))) * 8);
+                const f16x8 kh = *(const f16x8*)(Ks + o), kl = *(const f16x8*)(Ks + NKEY * D + o);
+                sx = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, ql[kk], sx, 0, 0, 0);
+                sm = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, qh[kk], sm, 0, 0, 0);
+                sx = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl, qh[kk], sx, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[kt][r] = fmaf(sx[r], SPLIT_LO_INV, sm[r]);
+            if ((kt & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = (kt * 16 + g * 4 + r < T) ? s[kt][r] * (scale * LOG2E) : -INFINITY;
+                s[kt][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const float e = exp2f(s[kt][r] - mx); s[kt][r] = e; sum += e; }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.f / sum;
+        f16x8 ph[NS], pl_[NS];
+#pragma unroll
+        for (int ss = 0; ss < NS; ++ss)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                _Float16 h0, l0, h1 = (_Float16)0.f, l1 = (_Float16)0.f;
+                split_f32(s[2 * ss][r] * inv, h0, l0);
+                if (2 * ss + 1 < NT) split_f32(s[(2 * ss + 1 < NT) ? 2 * ss + 1 : 0][r] * inv, h1, l1);
+                ph[ss][r] = h0; pl_[ss][r] = l0; ph[ss][4 + r] = h1; pl_[ss][4 + r] = l1;
+            }
+        f32x4 om[DT], ox[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) { om[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; ox[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int ss = 0; ss < NS; ++ss) {
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const int vo = (dt * 16 + fr) * VP + (((dt * 16 + fr) >> 3) & 7) * 8 + ss * 32 + g * 4;
+                const bool two = 2 * ss + 1 < NT;
+                const f16x4 a0 = *(const f16x4*)(Vt + vo), a1 = two ? *(const f16x4*)(Vt + vo + 16) : f16x4{0, 0, 0, 0};
+                const f16x4 b0 = *(const f16x4*)(Vt + D * VP + vo), b1 = two ? *(const f16x4*)(Vt + D * VP + vo + 16) : f16x4{0, 0, 0, 0};
+                const f16x8 vh = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+                const f16x8 vl = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+                ox[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, pl_[ss], ox[dt], 0, 0, 0);
+                om[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, ph[ss], om[dt], 0, 0, 0);
+                ox[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl, ph[ss], ox[dt], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (qrow < T) {
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                if (dt * 16 + g * 4 >= dm) continue;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaf(ox[dt][r], SPLIT_LO_INV, om[dt][r]);
+                store_h_rt<4>(ctx, ((long)b * T + qrow) * H + head * dm + dt * 16 + g * 4, ctx_lo, v);
+            }
+        }
+    }
+}
+
 }  // namespace advh
 
 using namespace advh;
@@ -272,5 +406,34 @@ extern "C" int advh_attention_f16(const void* qkv, void* ctx, int B, int T, int 
     }
 #undef ATT
 #undef ATT_TR
+    return ADVH_LAUNCH_CHECK();
+}
+
+static size_t att_x3_lds(int nt, int D) { return (size_t)2 * (nt * 16 * D + D * (nt * 16 + 64)) * 2; }
+
+// Raise the dynamic-LDS limit of the split attention instances (advh_init).
+int advh_init_attention() {
+#define X3A(NT_, D_)                                                                                                                \
+    if (hipFuncSetAttribute((const void*)attention_x3_kernel<NT_, D_>, hipFuncAttributeMaxDynamicSharedMemorySize,                  \
+                            (int)att_x3_lds(NT_, D_)) != hipSuccess) return ADVH_ELAUNCH;
+    X3A(4, 32) X3A(8, 32) X3A(13, 32) X3A(16, 32) X3A(4, 64) X3A(8, 64) X3A(13, 64) X3A(16, 64)
+#undef X3A
+    return ADVH_OK;
+}
+
+extern "C" int advh_attention_split(const void* qkv, int64_t qkv_lo, void* ctx, int64_t ctx_lo, int B, int T, int H, int heads,
+                                    advh_stream_t stream) {
+    if (!qkv || !ctx || B <= 0 || T <= 0 || heads <= 0 || H % heads || qkv_lo <= 0 || ctx_lo <= 0 || qkv_lo % 8 || ctx_lo % 4) return ADVH_EINVAL;
+    const int dm = H / heads;
+    if (T > 256 || dm % 8 || dm > 64) return ADVH_EUNSUPPORTED;
+    const int D = dm <= 32 ? 32 : 64;
+    const float scale = 1.f / sqrtf((float)dm);
+    dim3 grid(heads, B), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    const int nt = (T + 15) / 16;
+#define ATTX(NT_, D_) hipLaunchKernelGGL((attention_x3_kernel<NT_, D_>), grid, block, att_x3_lds(NT_, D_), s, (const _Float16*)qkv, (long)qkv_lo, (_Float16*)ctx, (long)ctx_lo, T, H, dm, scale)
+    if (D == 64) { if (nt <= 4) ATTX(4, 64); else if (nt <= 8) ATTX(8, 64); else if (nt <= 13) ATTX(13, 64); else ATTX(16, 64); }
+    else { if (nt <= 4) ATTX(4, 32); else if (nt <= 8) ATTX(8, 32); else if (nt <= 13) ATTX(13, 32); else ATTX(16, 32); }
+#undef ATTX
     return ADVH_LAUNCH_CHECK();
 }

@@ -27,4 +27,51 @@ __device__ __forceinline__ float gelu_grad(float x) {
 
 __device__ __forceinline__ float gelu_fast(float x) { return 0.5f * x * (1.f + fast_erf(x * 0.70710678118654752440f)); }
 
+// ---- split-precision ("x3") operand format of the fp32-class mode --------------------------------------------------
+// An fp32 value x travels between kernels as TWO fp16 planes: hi = fp16(x) and lo = fp16((x - hi) * 2^11), so that
+// x = hi + lo * 2^-11 to ~2^-22 relative (11 + 11 significand bits).  lo is pre-scaled by 2^11 to stay in fp16's normal
+// range (|lo| <= |hi|-ish instead of 2^-11 |hi|); values whose hi would be subnormal (|x| < 2^-14) are carried by lo alone
+// (absolute error there <= 2^-25 = 3e-8), so the result does not depend on how the matrix cores treat fp16 subnormals.  A product of two split
+// values is x*w = xh*wh + (xh*wl + xl*wh) * 2^-11 (+ xl*wl * 2^-22, dropped: <= 2^-22 relative): three fp16 MFMAs with fp32
+// accumulation, the cross terms in their own accumulator.  Every fp16 x fp16 product is exact in fp32.
+constexpr float SPLIT_LO_SCALE = 2048.f, SPLIT_LO_INV = 1.f / 2048.f;
+__device__ __forceinline__ void split_f32(float x, _Float16& hi, _Float16& lo) {
+    _Float16 h = (_Float16)x;
+    if (fabsf(x) < 6.103515625e-05f) h = (_Float16)0.f;
+    hi = h;
+    lo = (_Float16)((x - (float)h) * SPLIT_LO_SCALE);
+}
+__device__ __forceinline__ float join_f32(_Float16 hi, _Float16 lo) { return fmaf((float)lo, SPLIT_LO_INV, (float)hi); }
+
+// VW consecutive fp16 elements at base + o: plain fp16 (lo_off == 0) or the hi / lo plane pair (lo plane lo_off elements
+// behind).  The row kernels take lo_off as a run-time argument (uniform branch; they are HBM-bound).
+template <int VW>
+__device__ __forceinline__ void store_h_rt(_Float16* base, long o, long lo_off, const float (&v)[VW]) {
+    typedef _Float16 hvec __attribute__((ext_vector_type(VW)));
+    hvec hv, lv;
+    if (lo_off) {
+#pragma unroll
+        for (int r = 0; r < VW; ++r) { _Float16 h, l; split_f32(v[r], h, l); hv[r] = h; lv[r] = l; }
+        *(hvec*)(base + o) = hv;
+        *(hvec*)(base + o + lo_off) = lv;
+    } else {
+#pragma unroll
+        for (int r = 0; r < VW; ++r) hv[r] = (_Float16)v[r];
+        *(hvec*)(base + o) = hv;
+    }
+}
+template <int VW>
+__device__ __forceinline__ void load_h_rt(const _Float16* base, long o, long lo_off, float (&v)[VW]) {
+    typedef _Float16 hvec __attribute__((ext_vector_type(VW)));
+    const hvec hv = *(const hvec*)(base + o);
+    if (lo_off) {
+        const hvec lv = *(const hvec*)(base + o + lo_off);
+#pragma unroll
+        for (int r = 0; r < VW; ++r) v[r] = join_f32(hv[r], lv[r]);
+    } else {
+#pragma unroll
+        for (int r = 0; r < VW; ++r) v[r] = (float)hv[r];
+    }
+}
+
 }  // namespace advh

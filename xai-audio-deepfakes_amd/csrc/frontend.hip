@@ -148,7 +148,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ wave, long stride, int n_in, int L,
                                                     const float2* __restrict__ stats, const float* __restrict__ w0,
                                                     const float* __restrict__ bias, const float2* __restrict__ norm,
-                                                    _Float16* __restrict__ out, int T0, int P0, int C0, int mode) {
+                                                    _Float16* __restrict__ out, long out_lo, int T0, int P0, int C0, int mode) {
     __shared__ float xs[TT * S0 + K0];
     const int b = blockIdx.y, t0 = blockIdx.x * TT, tid = threadIdx.x;
     const float* w = wave + (long)b * stride;
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ wa
     }
     const int tend = min(TT, P0 - t0);
     for (int t = tsub; t < tend; t += tstep) {
-        f16x8 o = {0, 0, 0, 0, 0, 0, 0, 0};
+        float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (t0 + t < T0) {
             float x[K0];
 #pragma unroll
@@ -183,10 +183,10 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ wa
                 for (int k = 0; k < K0; ++k) y = fmaf(wr[j][k], x[k], y);
                 y = y * sc[j] + sh[j];
                 if (mode == 0) y = gelu_fast(y);
-                o[j] = (_Float16)y;
+                o[j] = y;
             }
         }
-        *(f16x8*)(out + ((long)b * P0 + t0 + t) * C0 + c) = o;
+        store_h_rt<8>(out, ((long)b * P0 + t0 + t) * C0 + c, out_lo, o);
     }
 }
 
@@ -194,9 +194,9 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ wa
 
 using namespace advh;
 
-extern "C" int advh_w2v2_frontend(const float* wave, int64_t wave_stride, int n_in, int B, int L, const float* w0,
-                                  const float* bias0, const float* gamma, const float* beta, int mode, int normalize, float* stats_ws,
-                                  float* norm_ws, float* mr_ws, void* out, int T0, int P0, int C0, advh_stream_t stream) {
+static int frontend_launch(const float* wave, int64_t wave_stride, int n_in, int B, int L, const float* w0,
+                           const float* bias0, const float* gamma, const float* beta, int mode, int normalize, float* stats_ws,
+                           float* norm_ws, float* mr_ws, void* out, int64_t out_lo, int T0, int P0, int C0, advh_stream_t stream) {
     if (!wave || !w0 || !stats_ws || !out || B <= 0 || L < K0 || n_in <= 0 || C0 <= 0 || C0 > 2048 || (C0 % 8) || 256 % (C0 / 8 < 256 ? C0 / 8 : 256)) return ADVH_EINVAL;
     if (T0 != (L - K0) / S0 + 1 || P0 < T0 || wave_stride < (n_in < L ? n_in : L)) return ADVH_EINVAL;
     if (mode == 0 && (!gamma || !beta || !norm_ws)) return ADVH_EINVAL;
@@ -207,6 +207,19 @@ extern "C" int advh_w2v2_frontend(const float* wave, int64_t wave_stride, int n_
         hipLaunchKernelGGL(gn_stats_kernel, dim3(B), dim3(256), 0, s, wave, (long)wave_stride, n_in, L,
                            (const float2*)stats_ws, w0, gamma, beta, (float2*)norm_ws, (float2*)mr_ws, T0, C0);
     hipLaunchKernelGGL(conv0_kernel, dim3((P0 + TT - 1) / TT, B), dim3(256), 0, s, wave, (long)wave_stride, n_in, L,
-                       (const float2*)stats_ws, w0, bias0, (const float2*)norm_ws, (_Float16*)out, T0, P0, C0, mode);
+                       (const float2*)stats_ws, w0, bias0, (const float2*)norm_ws, (_Float16*)out, (long)out_lo, T0, P0, C0, mode);
     return ADVH_LAUNCH_CHECK();
+}
+
+extern "C" int advh_w2v2_frontend(const float* wave, int64_t wave_stride, int n_in, int B, int L, const float* w0,
+                                  const float* bias0, const float* gamma, const float* beta, int mode, int normalize, float* stats_ws,
+                                  float* norm_ws, float* mr_ws, void* out, int T0, int P0, int C0, advh_stream_t stream) {
+    return frontend_launch(wave, wave_stride, n_in, B, L, w0, bias0, gamma, beta, mode, normalize, stats_ws, norm_ws, mr_ws, out, 0, T0, P0, C0, stream);
+}
+
+extern "C" int advh_w2v2_frontend_split(const float* wave, int64_t wave_stride, int n_in, int B, int L, const float* w0,
+                                        const float* bias0, const float* gamma, const float* beta, int mode, int normalize, float* stats_ws,
+                                        float* norm_ws, float* mr_ws, void* out, int64_t out_lo, int T0, int P0, int C0, advh_stream_t stream) {
+    if (out_lo <= 0 || out_lo % 8) return ADVH_EINVAL;
+    return frontend_launch(wave, wave_stride, n_in, B, L, w0, bias0, gamma, beta, mode, normalize, stats_ws, norm_ws, mr_ws, out, out_lo, T0, P0, C0, stream);
 }

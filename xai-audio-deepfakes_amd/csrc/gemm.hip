@@ -72,79 +72,100 @@ struct RowDecomp {
 // 32 (R>>5) + 8 ((R>>2)&3) + 4 ((R>>4)&1) + (R&3)), so the tile pair (2q, 2q+1) of a lane is 8 CONSECUTIVE channels:
 // 16-byte fp16 / 32-byte fp32 accesses, 64 / 128 contiguous bytes per row and instruction.
 // value path of one VW-wide group: bias, pre-activation copy, activation, activation-derivative factor
-template <int VW>
-__device__ __forceinline__ void epilogue_value(const advh_gemm_desc& p, float (&v)[VW], const float* bias, int n, long o) {
+// fp16-side accesses of the epilogue: plain fp16, or (SPLIT) the hi / lo plane pair of device_math.h's split format
+// (lo plane p.o_lo elements behind the hi plane, same addressing).
+template <int VW, bool SPLIT>
+__device__ __forceinline__ void store_h(void* base, long o, long o_lo, const float (&v)[VW]) {
     typedef _Float16 hvec __attribute__((ext_vector_type(VW)));
+    if constexpr (SPLIT) {
+        hvec hv, lv;
+#pragma unroll
+        for (int r = 0; r < VW; ++r) { _Float16 h, l; split_f32(v[r], h, l); hv[r] = h; lv[r] = l; }
+        *(hvec*)((_Float16*)base + o) = hv;
+        *(hvec*)((_Float16*)base + o + o_lo) = lv;
+    } else {
+        hvec hv;
+#pragma unroll
+        for (int r = 0; r < VW; ++r) hv[r] = (_Float16)v[r];
+        *(hvec*)((_Float16*)base + o) = hv;
+    }
+}
+template <int VW, bool SPLIT>
+__device__ __forceinline__ void load_h(const void* base, long o, long o_lo, float (&v)[VW]) {
+    typedef _Float16 hvec __attribute__((ext_vector_type(VW)));
+    const hvec hv = *(const hvec*)((const _Float16*)base + o);
+    if constexpr (SPLIT) {
+        const hvec lv = *(const hvec*)((const _Float16*)base + o + o_lo);
+#pragma unroll
+        for (int r = 0; r < VW; ++r) v[r] = join_f32(hv[r], lv[r]);
+    } else {
+#pragma unroll
+        for (int r = 0; r < VW; ++r) v[r] = (float)hv[r];
+    }
+}
+
+template <int VW, bool SPLIT = false>
+__device__ __forceinline__ void epilogue_value(const advh_gemm_desc& p, float (&v)[VW], const float* bias, int n, long o) {
     if (bias) {
 #pragma unroll
         for (int c = 0; c < VW; c += 4) { float4 bb = *(const float4*)(bias + n + c); v[c] += bb.x; v[c + 1] += bb.y; v[c + 2] += bb.z; v[c + 3] += bb.w; }
     }
-    if (p.out_pre) {
-        hvec pv;
-#pragma unroll
-        for (int r = 0; r < VW; ++r) pv[r] = (_Float16)v[r];
-        *(hvec*)((_Float16*)p.out_pre + o) = pv;
-    }
+    if (p.out_pre) store_h<VW, SPLIT>(p.out_pre, o, p.o_lo, v);
 #pragma unroll
     for (int r = 0; r < VW; ++r) v[r] = apply_act(v[r], p.act, p.slope);
     if (p.dact_src) {
-        hvec zz = *(const hvec*)((const _Float16*)p.dact_src + o);
+        float zz[VW];
+        load_h<VW, SPLIT>(p.dact_src, o, p.o_lo, zz);
 #pragma unroll
-        for (int r = 0; r < VW; ++r) v[r] *= gelu_grad((float)zz[r]);
+        for (int r = 0; r < VW; ++r) v[r] *= gelu_grad(zz[r]);
     }
 }
 
-template <int VW>
+template <int VW, bool SPLIT = false>
 __device__ __forceinline__ void epilogue_resid(const advh_gemm_desc& p, float (&v)[VW], long o) {
-    typedef _Float16 hvec __attribute__((ext_vector_type(VW)));
     if (p.resid) {
         if (p.resid_f32) {
 #pragma unroll
             for (int c = 0; c < VW; c += 4) { float4 rr = *(const float4*)((const float*)p.resid + o + c); v[c] += rr.x; v[c + 1] += rr.y; v[c + 2] += rr.z; v[c + 3] += rr.w; }
         } else {
-            hvec rr = *(const hvec*)((const _Float16*)p.resid + o);
+            float rr[VW];
+            load_h<VW, SPLIT>(p.resid, o, p.o_lo, rr);
 #pragma unroll
-            for (int r = 0; r < VW; ++r) v[r] += (float)rr[r];
+            for (int r = 0; r < VW; ++r) v[r] += rr[r];
         }
     }
 }
 
-template <int VW>
+template <int VW, bool SPLIT = false>
 __device__ __forceinline__ void epilogue_write(const advh_gemm_desc& p, float (&v)[VW], long o) {
-    typedef _Float16 hvec __attribute__((ext_vector_type(VW)));
     if (p.out_f) {
 #pragma unroll
         for (int c = 0; c < VW; c += 4) *(float4*)((float*)p.out_f + o + c) = make_float4(v[c], v[c + 1], v[c + 2], v[c + 3]);
     }
-    if (p.out_h) {
-        hvec hv;
-#pragma unroll
-        for (int r = 0; r < VW; ++r) hv[r] = (_Float16)v[r];
-        *(hvec*)((_Float16*)p.out_h + o) = hv;
-    }
+    if (p.out_h) store_h<VW, SPLIT>(p.out_h, o, p.o_lo, v);
     if (p.out_h2) {
-        hvec hv;
+        float w[VW];
 #pragma unroll
-        for (int r = 0; r < VW; ++r) hv[r] = (_Float16)(v[r] > 0.f ? v[r] : p.slope2 * v[r]);
-        *(hvec*)((_Float16*)p.out_h2 + o) = hv;
+        for (int r = 0; r < VW; ++r) w[r] = v[r] > 0.f ? v[r] : p.slope2 * v[r];
+        store_h<VW, SPLIT>(p.out_h2, o, p.o_lo, w);
     }
 }
 
-template <int VW>
+template <int VW, bool SPLIT = false>
 __device__ __forceinline__ void epilogue_store(const advh_gemm_desc& p, float (&v)[VW], bool ok, const float* bias, int n, long o) {
     if (ok) {
-        epilogue_value<VW>(p, v, bias, n, o);
-        epilogue_resid<VW>(p, v, o);
+        epilogue_value<VW, SPLIT>(p, v, bias, n, o);
+        epilogue_resid<VW, SPLIT>(p, v, o);
     } else {
 #pragma unroll
         for (int r = 0; r < VW; ++r) v[r] = 0.f;
     }
-    epilogue_write<VW>(p, v, o);
+    epilogue_write<VW, SPLIT>(p, v, o);
 }
 
 // Lean form for desc.plain_out (every row valid, output row m at o_c0 + m * o_sW, one column block): no row
 // decomposition, no runtime divisions -- the epilogue of the Linear layers, where K = 768 makes it 10-30 % of a tile.
-template <int MI, int NI>
+template <int MI, int NI, bool SPLIT = false>
 __device__ __forceinline__ void gemm_epilogue_lean(const advh_gemm_desc& p, f32x4 (&acc)[NI][MI], int mw0, int nw0, int fr, int fq, int z,
                                                    long zo) {
     const float* bias = p.bias ? p.bias + (long)p.bias_sZ * z : nullptr;
@@ -170,9 +191,7 @@ __device__ __forceinline__ void gemm_epilogue_lean(const advh_gemm_desc& p, f32x
                         rv[q][0] = r0.x; rv[q][1] = r0.y; rv[q][2] = r0.z; rv[q][3] = r0.w;
                         rv[q][4] = r1.x; rv[q][5] = r1.y; rv[q][6] = r1.z; rv[q][7] = r1.w;
                     } else {
-                        const f16x8 rr = *(const f16x8*)((const _Float16*)p.resid + o);
-#pragma unroll
-                        for (int r = 0; r < 8; ++r) rv[q][r] = (float)rr[r];
+                        load_h<8, SPLIT>(p.resid, o, p.o_lo, rv[q]);
                     }
                 }
             }
@@ -183,12 +202,12 @@ __device__ __forceinline__ void gemm_epilogue_lean(const advh_gemm_desc& p, f32x
                 float v[8];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { v[r] = acc[2 * q][mi][r]; v[4 + r] = acc[2 * q + 1][mi][r]; }
-                epilogue_value<8>(p, v, bias, n, orow + n);
+                epilogue_value<8, SPLIT>(p, v, bias, n, orow + n);
                 if (pre) {
 #pragma unroll
                     for (int r = 0; r < 8; ++r) v[r] += rv[q][r];
                 }
-                epilogue_write<8>(p, v, orow + n);
+                epilogue_write<8, SPLIT>(p, v, orow + n);
             }
         }
         return;
@@ -203,12 +222,12 @@ __device__ __forceinline__ void gemm_epilogue_lean(const advh_gemm_desc& p, f32x
             const int n = nw0 + ni * 16 + fq * 4;
             if (n >= p.N) continue;
             float v[4] = {acc[ni][mi][0], acc[ni][mi][1], acc[ni][mi][2], acc[ni][mi][3]};
-            epilogue_store<4>(p, v, true, bias, n, orow + n);
+            epilogue_store<4, SPLIT>(p, v, true, bias, n, orow + n);
         }
     }
 }
 
-template <int MI, int NI>
+template <int MI, int NI, bool SPLIT = false>
 __device__ __forceinline__ void gemm_epilogue(const advh_gemm_desc& p, f32x4 (&acc)[NI][MI], int mw0, int nw0, int fr, int fq, int z,
                                               long zo = -1) {          // zo: output offset of batch z (default o_sZ * z)
     static_assert(NI % 2 == 0, "the wide epilogue pairs n-tiles");
@@ -242,7 +261,7 @@ __device__ __forceinline__ void gemm_epilogue(const advh_gemm_desc& p, f32x4 (&a
                 float v[8];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { v[r] = acc[2 * q][mi][r]; v[4 + r] = acc[2 * q + 1][mi][r]; }
-                epilogue_store<8>(p, v, ok, bias, n, o);
+                epilogue_store<8, SPLIT>(p, v, ok, bias, n, o);
             }
         } else {
 #pragma unroll
@@ -260,7 +279,7 @@ __device__ __forceinline__ void gemm_epilogue(const advh_gemm_desc& p, f32x4 (&a
                     o = orow + (p.n_sub > 1 ? (long)(qn / p.n_sub) * p.o_sNhh + (long)(qn % p.n_sub) * p.o_sNhi : (long)qn * p.o_sNhi) + (n % p.n_div);
                 }
                 float v[4] = {acc[ni][mi][0], acc[ni][mi][1], acc[ni][mi][2], acc[ni][mi][3]};
-                epilogue_store<4>(p, v, ok, bias, n, o);
+                epilogue_store<4, SPLIT>(p, v, ok, bias, n, o);
             }
         }
     }
@@ -443,6 +462,188 @@ static int launch(const advh_gemm_desc& d, hipStream_t s) {
         }
     }
     hipLaunchKernelGGL((gemm_f16_kernel<BM, BN, WM, WN, WPE>), grid, dim3(64 * WM * WN), 0, s, d);
+    return ADVH_LAUNCH_CHECK();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// fp32-class instance ("x3"): both operands arrive in the split format of device_math.h (hi plane + lo plane, the lo
+// plane a fixed distance behind: desc.a_lo / w_lo), the four planes of a K-step are staged by the same LDS DMA with the
+// same swizzle, and every (weight fragment, activation fragment) pair costs three MFMAs:
+//     acc  += Wh * Ah                       (leading term)
+//     accx += Wh * Al + Wl * Ah             (cross terms, carry 2^-11; the Wl * Al term, <= 2^-22 relative, is dropped)
+// result = acc + accx * 2^-11: every product is exact in fp32, so the only rounding is the fp32 accumulation -- the
+// arithmetic class of the reference's fp32 convolutions / Linears (addvisor.py:12-84, modeling_wav2vec2.py:254-572),
+// at 1/3 of the fp16 MFMA rate (833 TFLOP/s dense peak) instead of the 157 TFLOP/s of v_mfma_f32_*_f32.
+// 64 KiB of LDS per 128 x 128 K-step and 2 x 64 accumulator registers => two workgroups per CU.
+template <int BM, int BN, int WM, int WN, bool PLAIN>
+__global__ __launch_bounds__(64 * WM * WN, 2) void gemm_x3_kernel(const advh_gemm_desc p) {
+    constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 16, NI = TN / 16;
+    constexpr int NT = 64 * WM * WN, RPP = NT / 8;
+    constexpr int NA = BM / RPP, NB = BN / RPP;
+    constexpr int PA = BM * BK * 2, PB = BN * BK * 2;   // bytes of one plane of a K-step
+    static_assert(NA >= 1 && NB >= 1 && BM % RPP == 0 && BN % RPP == 0, "loader passes");
+    extern __shared__ __attribute__((aligned(16))) char dsm3[];
+    char* ldsA = dsm3;                                  // [A hi | A lo | W hi | W lo]
+    char* ldsB = dsm3 + 2 * PA;
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wm = wv / WN, wn = wv % WN;
+    const int tilesN = (p.N + BN - 1) / BN;
+    int nwg = gridDim.x;
+    int id = blockIdx.x;
+    {
+        const int q8 = nwg / 8, r8 = nwg % 8, xcd = id % 8;
+        id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + id / 8;
+    }
+    int z = blockIdx.z;
+    if (p.z_inner) {
+        z = id % p.nz;
+        id /= p.nz;
+        nwg /= p.nz;
+    }
+    int tile_n, tile_m;
+    {
+        const int tilesM = nwg / tilesN, sc = (p.sc > 0 && p.sc < tilesN) ? p.sc : tilesN;
+        const int s = id / (tilesM * sc), rem = id - s * tilesM * sc;
+        const int wcols = min(sc, tilesN - s * sc);
+        tile_m = rem / wcols;
+        tile_n = s * sc + rem - tile_m * wcols;
+    }
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int zh = p.nz_lo > 1 ? z / p.nz_lo : z, zw = p.nz_lo > 1 ? z % p.nz_lo : 0;
+
+    const _Float16* A0 = (const _Float16*)p.A0 + (p.a_sZ[0] * zh + p.a_sZ2[0] * zw) * 8;
+    const _Float16* A1 = (const _Float16*)p.A1 + (p.a_sZ[1] * zh + p.a_sZ2[1] * zw) * 8;
+    const _Float16* Wp = (const _Float16*)p.W + p.w_sZ * z;
+    const long alo0 = p.a_lo[0] * 8, alo1 = p.a_lo[1] * 8, wlo = p.w_lo;
+
+    const int ldrow = tid >> 3;
+    const int q = (tid & 7) ^ (ldrow & 7);
+    unsigned rb0[PLAIN ? 1 : NA], rb1[PLAIN ? 1 : NA];
+    const _Float16* wrow[PLAIN ? 1 : NB];
+    const _Float16* ap[PLAIN ? NA : 1];
+    const _Float16* wp0 = nullptr;
+    long wstep = 0;
+    if constexpr (PLAIN) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int m = min(m0 + ldrow + RPP * i, p.M - 1);
+            ap[i] = A0 + ((long)m * p.a_sW[0] + p.a_c0[0] + q) * 8;
+        }
+        const long wld = p.w_ld ? p.w_ld : (long)p.Ktot;
+        wp0 = Wp + (long)(n0 + ldrow) * wld + q * 8;
+        wstep = (long)RPP * wld;
+    } else {
+        long safe0 = (long)p.h0 * p.a_sH[0] + (long)p.w0 * p.a_sW[0] + p.a_c0[0];
+        long safe1 = (long)p.h0 * p.a_sH[1] + (long)p.w0 * p.a_sW[1] + p.a_c0[1];
+        const RowDecomp rd(p.Wg, p.Hg);
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            unsigned m = m0 + ldrow + RPP * i;
+            unsigned w, h, b;
+            rd(m, b, h, w);
+            bool ok = m < (unsigned)p.M && (int)h >= p.h0 && (int)h < p.h1 && (int)w >= p.w0 && (int)w < p.w1;
+            long r0 = ok ? (long)b * p.a_sB[0] + (long)h * p.a_sH[0] + (long)w * p.a_sW[0] + p.a_c0[0] : safe0;
+            long r1 = ok ? (long)b * p.a_sB[1] + (long)h * p.a_sH[1] + (long)w * p.a_sW[1] + p.a_c0[1] : safe1;
+            rb0[i] = (unsigned)r0;
+            rb1[i] = (unsigned)r1;
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) wrow[i] = Wp + (long)(n0 + ldrow + RPP * i) * (p.w_ld ? p.w_ld : (long)p.Ktot) + q * 8;
+    }
+
+    const int fr = lane & 15, fq = lane >> 4;
+    int offA[2], offB[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        int c = (kk * 4 + fq) ^ (fr & 7);
+        offA[kk] = ((wm * TM + fr) * 8 + c) * 16;
+        offB[kk] = ((wn * TN + fr) * 8 + c) * 16;
+    }
+
+    f32x4 acc[NI][MI], accx[NI][MI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) { acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f}; accx[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+    const int nk = p.Ktot / BK;
+    int kq = PLAIN ? 0 : p.ktab[q];
+    for (int kt = 0; kt < nk; ++kt) {
+        if constexpr (PLAIN) {
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                __builtin_amdgcn_global_load_lds(GLOBAL_PTR(ap[i] + kt * BK), LDS_PTR(ldsA + (wv * 64 + NT * i) * 16), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(GLOBAL_PTR(ap[i] + alo0 + kt * BK), LDS_PTR(ldsA + PA + (wv * 64 + NT * i) * 16), 16, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                __builtin_amdgcn_global_load_lds(GLOBAL_PTR(wp0 + i * wstep + kt * BK), LDS_PTR(ldsB + (wv * 64 + NT * i) * 16), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(GLOBAL_PTR(wp0 + wlo + i * wstep + kt * BK), LDS_PTR(ldsB + PB + (wv * 64 + NT * i) * 16), 16, 0, 0);
+            }
+        } else {
+            const bool s1 = kq < 0;
+            const unsigned ko = (unsigned)kq & 0x7fffffffu;
+            const _Float16* base = s1 ? A1 : A0;
+            const long alo = s1 ? alo1 : alo0;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const _Float16* g = base + ((unsigned long)((s1 ? rb1[i] : rb0[i]) + ko)) * 8;
+                __builtin_amdgcn_global_load_lds(GLOBAL_PTR(g), LDS_PTR(ldsA + (wv * 64 + NT * i) * 16), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(GLOBAL_PTR(g + alo), LDS_PTR(ldsA + PA + (wv * 64 + NT * i) * 16), 16, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                __builtin_amdgcn_global_load_lds(GLOBAL_PTR(wrow[i] + kt * BK), LDS_PTR(ldsB + (wv * 64 + NT * i) * 16), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(GLOBAL_PTR(wrow[i] + wlo + kt * BK), LDS_PTR(ldsB + PB + (wv * 64 + NT * i) * 16), 16, 0, 0);
+            }
+            if (kt + 1 < nk) kq = p.ktab[(kt + 1) * 8 + q];
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            f16x8 bh[NI], bl[NI];
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                bh[ni] = *(const f16x8*)(ldsB + offB[kk] + ni * 16 * 128);
+                bl[ni] = *(const f16x8*)(ldsB + PB + offB[kk] + ni * 16 * 128);
+            }
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                const f16x8 ah = *(const f16x8*)(ldsA + offA[kk] + mi * 16 * 128);
+                const f16x8 al = *(const f16x8*)(ldsA + PA + offA[kk] + mi * 16 * 128);
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) accx[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[ni], al, accx[ni][mi], 0, 0, 0);
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[ni], ah, acc[ni][mi], 0, 0, 0);
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) accx[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[ni], ah, accx[ni][mi], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[ni][mi][r] = fmaf(accx[ni][mi][r], SPLIT_LO_INV, acc[ni][mi][r]);
+
+    if (PLAIN && p.plain_out) gemm_epilogue_lean<MI, NI, true>(p, acc, m0 + wm * TM, n0 + wn * TN, fr, fq, z, p.o_sZ * zh + p.o_sZ2 * zw);
+    else gemm_epilogue<MI, NI, true>(p, acc, m0 + wm * TM, n0 + wn * TN, fr, fq, z, p.o_sZ * zh + p.o_sZ2 * zw);
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch_x3(const advh_gemm_desc& d, hipStream_t s) {
+    const int tilesM = (d.M + BM - 1) / BM, tilesN = (d.N + BN - 1) / BN;
+    if (tilesN * BN > d.w_rows) return ADVH_EINVAL;
+    const int nz = d.nz > 0 ? d.nz : 1;
+    if (d.z_inner && (long)tilesM * tilesN * nz > 0x7fffffffL) return ADVH_EINVAL;
+    dim3 grid(d.z_inner ? tilesM * tilesN * nz : tilesM * tilesN, 1, d.z_inner ? 1 : nz);
+    constexpr int lds = 2 * (BM + BN) * BK * 2;
+    if (d.plain) hipLaunchKernelGGL((gemm_x3_kernel<BM, BN, WM, WN, true>), grid, dim3(64 * WM * WN), lds, s, d);
+    else hipLaunchKernelGGL((gemm_x3_kernel<BM, BN, WM, WN, false>), grid, dim3(64 * WM * WN), lds, s, d);
     return ADVH_LAUNCH_CHECK();
 }
 
@@ -936,6 +1137,12 @@ int advh_init_rest() {
     if (hipFuncSetAttribute((const void*)gemm_f16_ring_kernel<256, 256, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, maxlds) != hipSuccess) return ADVH_ELAUNCH;
     if (hipFuncSetAttribute((const void*)gemm_f16_pipe_kernel<256, 256, 2, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, maxlds) != hipSuccess) return ADVH_ELAUNCH;
     if (hipFuncSetAttribute((const void*)gemm_f16_persist_kernel<256, 128, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, maxlds) != hipSuccess) return ADVH_ELAUNCH;
+#define X3_ATTR(BM_, BN_, WM_, WN_)                                                                                                        \
+    if (hipFuncSetAttribute((const void*)gemm_x3_kernel<BM_, BN_, WM_, WN_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, maxlds) != hipSuccess || \
+        hipFuncSetAttribute((const void*)gemm_x3_kernel<BM_, BN_, WM_, WN_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, maxlds) != hipSuccess)   \
+        return ADVH_ELAUNCH;
+    X3_ATTR(128, 128, 2, 2) X3_ATTR(256, 64, 4, 1) X3_ATTR(256, 32, 4, 1)
+#undef X3_ATTR
     return ADVH_OK;
 }
 
@@ -955,6 +1162,15 @@ extern "C" int advh_gemm_f16(const advh_gemm_desc* d, int tile, advh_stream_t st
     if ((d->nz_lo > 1 || d->z_inner) && (tile == ADVH_TILE_256x256 || tile == ADVH_TILE_256x256_RING || tile == ADVH_TILE_256x128 ||
                                           tile == ADVH_TILE_256x128_PERSIST || tile == ADVH_TILE_256x256_W4))
         return ADVH_EUNSUPPORTED;                        // the two-level batch lives in gemm_f16_kernel only
+    if (d->split) {                                      // fp32-class instance: split-format operands, 3 MFMAs per fragment pair
+        if (d->out_pre || d->dact_src) return ADVH_EUNSUPPORTED;      // the backward chain runs on the fp16 instances
+        switch (tile) {
+            case ADVH_TILE_128x128: return launch_x3<128, 128, 2, 2>(*d, s);
+            case ADVH_TILE_256x64: return launch_x3<256, 64, 4, 1>(*d, s);
+            case ADVH_TILE_256x32: return launch_x3<256, 32, 4, 1>(*d, s);
+            default: return ADVH_EUNSUPPORTED;
+        }
+    }
     switch (tile) {
         case ADVH_TILE_128x128: return launch<128, 128, 2, 2, 3>(*d, s);
         case ADVH_TILE_256x64: return launch<256, 64, 4, 1, 3>(*d, s);

@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const void* __restrict__
                                                         const _Float16* __restrict__ add_h, long add_ld,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         float* __restrict__ out_f, _Float16* __restrict__ out_h, long out_ld,
-                                                        int M, int C, float eps, int gelu) {
+                                                        int M, int C, float eps, int gelu, long in_lo, long add_lo, long out_lo) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -41,14 +41,13 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const void* __restrict__
                 float4 t = *(const float4*)((const float*)in + row * in_ld + c);
                 v[i][0] = t.x; v[i][1] = t.y; v[i][2] = t.z; v[i][3] = t.w;
             } else {
-                f16x4 t = *(const f16x4*)((const _Float16*)in + row * in_ld + c);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[i][r] = (float)t[r];
+                load_h_rt<4>((const _Float16*)in, row * in_ld + c, in_lo, v[i]);
             }
             if (add_h) {                                  // x = in + branch (the fp16 output of the preceding projection)
-                f16x4 t = *(const f16x4*)(add_h + row * add_ld + c);
+                float t[4];
+                load_h_rt<4>(add_h, row * add_ld + c, add_lo, t);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[i][r] += (float)t[r];
+                for (int r = 0; r < 4; ++r) v[i][r] += t[r];
             }
             s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
         } else {
@@ -78,10 +77,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const void* __restrict__
                 for (int r = 0; r < 4; ++r) o[r] = gelu_fast(o[r]);
             }
             if (out_f) *(float4*)(out_f + row * out_ld + c) = make_float4(o[0], o[1], o[2], o[3]);
-            if (out_h) {
-                f16x4 h = {(_Float16)o[0], (_Float16)o[1], (_Float16)o[2], (_Float16)o[3]};
-                *(f16x4*)(out_h + row * out_ld + c) = h;
-            }
+            if (out_h) store_h_rt<4>(out_h, row * out_ld + c, out_lo, o);
         }
     }
 }
@@ -90,7 +86,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const void* __restrict__
 // (the zero padding of the positional Conv1d, modeling_wav2vec2.py:326-379).
 __global__ __launch_bounds__(256) void posconv_gather_kernel(const float* __restrict__ h, _Float16* __restrict__ xg,
                                                              int B, int T, int H, int G, int K, int pad_left,
-                                                             const _Float16* __restrict__ dact_src) {
+                                                             const _Float16* __restrict__ dact_src, long xg_lo) {
     const int Cg = H / G, P = T + K, c4 = Cg / 4;
     const long total = (long)G * B * P * c4;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -100,7 +96,7 @@ __global__ __launch_bounds__(256) void posconv_gather_kernel(const float* __rest
         long gb = r / P;
         int b = (int)(gb % B), g = (int)(gb / B);
         int t = p - pad_left;
-        f16x4 o = {0, 0, 0, 0};
+        float o[4] = {0.f, 0.f, 0.f, 0.f};
         if (t >= 0 && t < T) {
             const long src = ((long)b * T + t) * H + g * Cg + c;
             float4 v = *(const float4*)(h + src);
@@ -109,9 +105,9 @@ __global__ __launch_bounds__(256) void posconv_gather_kernel(const float* __rest
                 v.x *= gelu_grad((float)z[0]); v.y *= gelu_grad((float)z[1]);
                 v.z *= gelu_grad((float)z[2]); v.w *= gelu_grad((float)z[3]);
             }
-            o = f16x4{(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+            o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
         }
-        *(f16x4*)(xg + r * Cg + c) = o;
+        store_h_rt<4>(xg, r * Cg + c, xg_lo, o);
     }
 }
 
@@ -198,9 +194,9 @@ __global__ __launch_bounds__(256) void pool_logreg_kernel(const float* __restric
 
 using namespace advh;
 
-extern "C" int advh_layernorm_add(const void* in, int in_is_f32, int64_t in_ld, const void* add_h, int64_t add_ld,
-                                  const float* gamma, const float* beta, float* out_f, void* out_h, int64_t out_ld, int M, int C,
-                                  float eps, int gelu, advh_stream_t stream) {
+static int layernorm_launch(const void* in, int in_is_f32, int64_t in_ld, const void* add_h, int64_t add_ld,
+                            const float* gamma, const float* beta, float* out_f, void* out_h, int64_t out_ld, int M, int C,
+                            float eps, int gelu, int64_t in_lo, int64_t add_lo, int64_t out_lo, advh_stream_t stream) {
     if (!in || !gamma || !beta || (!out_f && !out_h) || M <= 0 || C <= 0 || C % 4 || in_ld % 4 || out_ld % 4 || (add_h && add_ld % 4))
         return ADVH_EINVAL;
     if (C > 64 * 4 * 8) return ADVH_EUNSUPPORTED;
@@ -208,12 +204,26 @@ extern "C" int advh_layernorm_add(const void* in, int in_is_f32, int64_t in_ld, 
     hipStream_t s = (hipStream_t)stream;
 #define LN_LAUNCH(F32, MV)                                                                                         \
     hipLaunchKernelGGL((layernorm_kernel<F32, MV>), grid, block, 0, s, in, (long)in_ld, (const _Float16*)add_h,   \
-                       (long)add_ld, gamma, beta, out_f, (_Float16*)out_h, (long)out_ld, M, C, eps, gelu)
+                       (long)add_ld, gamma, beta, out_f, (_Float16*)out_h, (long)out_ld, M, C, eps, gelu, (long)in_lo, (long)add_lo, (long)out_lo)
     if (C <= 64 * 4 * 2) { if (in_is_f32) LN_LAUNCH(true, 2); else LN_LAUNCH(false, 2); }
     else if (C <= 64 * 4 * 4) { if (in_is_f32) LN_LAUNCH(true, 4); else LN_LAUNCH(false, 4); }
     else { if (in_is_f32) LN_LAUNCH(true, 8); else LN_LAUNCH(false, 8); }
 #undef LN_LAUNCH
     return ADVH_LAUNCH_CHECK();
+}
+
+extern "C" int advh_layernorm_add(const void* in, int in_is_f32, int64_t in_ld, const void* add_h, int64_t add_ld,
+                                  const float* gamma, const float* beta, float* out_f, void* out_h, int64_t out_ld, int M, int C,
+                                  float eps, int gelu, advh_stream_t stream) {
+    return layernorm_launch(in, in_is_f32, in_ld, add_h, add_ld, gamma, beta, out_f, out_h, out_ld, M, C, eps, gelu, 0, 0, 0, stream);
+}
+
+extern "C" int advh_layernorm_split(const void* in, int in_is_f32, int64_t in_ld, int64_t in_lo, const void* add_h, int64_t add_ld,
+                                    int64_t add_lo, const float* gamma, const float* beta, float* out_f, void* out_h, int64_t out_ld,
+                                    int64_t out_lo, int M, int C, float eps, int gelu, advh_stream_t stream) {
+    if ((!in_is_f32 && in_lo <= 0) || (add_h && add_lo <= 0) || (out_h && out_lo <= 0) || in_lo % 4 || add_lo % 4 || out_lo % 4) return ADVH_EINVAL;
+    return layernorm_launch(in, in_is_f32, in_ld, add_h, add_ld, gamma, beta, out_f, out_h, out_ld, M, C, eps, gelu,
+                            in_is_f32 ? 0 : in_lo, add_h ? add_lo : 0, out_h ? out_lo : 0, stream);
 }
 
 extern "C" int advh_layernorm(const void* in, int in_is_f32, int64_t in_ld, const float* gamma, const float* beta,
@@ -222,15 +232,26 @@ extern "C" int advh_layernorm(const void* in, int in_is_f32, int64_t in_ld, cons
     return advh_layernorm_add(in, in_is_f32, in_ld, nullptr, 0, gamma, beta, out_f, out_h, out_ld, M, C, eps, gelu, stream);
 }
 
-extern "C" int advh_posconv_gather(const float* h, void* xg, int B, int T, int H, int G, int K, int pad_left,
-                                   const void* dact_src, advh_stream_t stream) {
+static int posconv_gather_launch(const float* h, void* xg, int64_t xg_lo, int B, int T, int H, int G, int K, int pad_left,
+                                 const void* dact_src, advh_stream_t stream) {
     if (!h || !xg || B <= 0 || T <= 0 || H <= 0 || G <= 0 || H % G || (H / G) % 8 || K <= 0 || K % 2 || pad_left < 0 || pad_left > K) return ADVH_EINVAL;
     long total = (long)G * B * (T + K) * (H / G / 4);
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(posconv_gather_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, h, (_Float16*)xg, B, T, H, G, K, pad_left,
-                       (const _Float16*)dact_src);
+                       (const _Float16*)dact_src, (long)xg_lo);
     return ADVH_LAUNCH_CHECK();
+}
+
+extern "C" int advh_posconv_gather(const float* h, void* xg, int B, int T, int H, int G, int K, int pad_left,
+                                   const void* dact_src, advh_stream_t stream) {
+    return posconv_gather_launch(h, xg, 0, B, T, H, G, K, pad_left, dact_src, stream);
+}
+
+extern "C" int advh_posconv_gather_split(const float* h, void* xg, int64_t xg_lo, int B, int T, int H, int G, int K, int pad_left,
+                                         advh_stream_t stream) {
+    if (xg_lo <= 0 || xg_lo % 4) return ADVH_EINVAL;
+    return posconv_gather_launch(h, xg, xg_lo, B, T, H, G, K, pad_left, nullptr, stream);
 }
 
 extern "C" int advh_pool_logreg(const float* h, const float* coef, float intercept, float* logit, float* prob,

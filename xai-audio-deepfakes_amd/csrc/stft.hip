@@ -330,6 +330,8 @@ extern "C" int advh_init(void) {
         if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, maxlds) != hipSuccess) return ADVH_ELAUNCH;
     int rc = advh_init_rest();
     if (rc != ADVH_OK) return rc;
+    rc = advh_init_attention();
+    if (rc != ADVH_OK) return rc;
     g_init_done = true;
     return ADVH_OK;
 }

@@ -7,6 +7,7 @@
 #include <hip/hip_fp16.h>
 #include "addvisor_hip.h"
 #include "common.h"
+#include "device_math.h"
 
 namespace advh {
 
@@ -17,7 +18,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 __global__ __launch_bounds__(256) void unet_stem_kernel(const float* __restrict__ mag, int Fq, int Tq, int H, int W,
                                                         const float* __restrict__ wgt /*[32][15]*/,
                                                         const float* __restrict__ bias, _Float16* __restrict__ out,
-                                                        int PH, int PW, float slope, long total) {
+                                                        int PH, int PW, float slope, long total, long out_lo) {
     __shared__ float ws[32 * 15 + 32];
     for (int i = threadIdx.x; i < 32 * 15 + 32; i += 256) ws[i] = i < 480 ? wgt[i] : bias[i - 480];
     __syncthreads();
@@ -35,19 +36,19 @@ __global__ __launch_bounds__(256) void unet_stem_kernel(const float* __restrict_
             int h = 2 * ho + kh - 2, ww = w + kw - 1;
             x[kh * 3 + kw] = (h >= 0 && h < H && ww >= 0 && ww < W) ? mag[((long)b * Fq + h) * Tq + ww] : 0.f;
         }
-    _Float16* o = out + (((long)b * (Ho + 2 * PH) + ho + PH) * (W + 2 * PW) + w + PW) * 32;
+    const long o = (((long)b * (Ho + 2 * PH) + ho + PH) * (W + 2 * PW) + w + PW) * 32;
 #pragma unroll
     for (int c8 = 0; c8 < 4; ++c8) {
-        f16x8 v;
+        float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             int c = c8 * 8 + j;
             float y = ws[480 + c];
 #pragma unroll
             for (int k = 0; k < 15; ++k) y = fmaf(ws[c * 15 + k], x[k], y);
-            v[j] = (_Float16)(y > 0.f ? y : slope * y);
+            v[j] = y > 0.f ? y : slope * y;
         }
-        *(f16x8*)(o + c8 * 8) = v;
+        store_h_rt<8>(out, o + c8 * 8, out_lo, v);
     }
 }
 
@@ -55,32 +56,33 @@ __global__ __launch_bounds__(256) void unet_stem_kernel(const float* __restrict_
 // The 1 is the in-image indicator of the fused up-convolution (zero in the halo, which is never written); the unfused
 // path pairs that channel with zero weights.
 __global__ __launch_bounds__(256) void unet_pack_x_kernel(const float* __restrict__ mag, int Fq, int Tq, int H, int W,
-                                                          _Float16* __restrict__ cat, int C, int c0, int PH, int PW, long total) {
+                                                          _Float16* __restrict__ cat, int C, int c0, int PH, int PW, long total, long cat_lo) {
     long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
     int w = (int)(i % W);
     long r = i / W;
     int h = (int)(r % H), b = (int)(r / H);
-    f16x8 v = {(_Float16)mag[((long)b * Fq + h) * Tq + w], (_Float16)1.0f, 0, 0, 0, 0, 0, 0};
-    *(f16x8*)(cat + (((long)b * (H + 2 * PH) + h + PH) * (W + 2 * PW) + w + PW) * C + c0) = v;
+    const float v[8] = {mag[((long)b * Fq + h) * Tq + w], 1.0f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    store_h_rt<8>(cat, (((long)b * (H + 2 * PH) + h + PH) * (W + 2 * PW) + w + PW) * C + c0, cat_lo, v);
 }
 
 // mask[b][h][w] = sigmoid(sum_c y[b,h,w,c] * w[c] + bias)   (mask_head, addvisor.py:57-60); fp32 out, w fastest
 __global__ __launch_bounds__(256) void unet_head_kernel(const _Float16* __restrict__ y, int H, int W, int PH, int PW,
                                                         const float* __restrict__ wgt, float bias,
-                                                        float* __restrict__ mask, float* __restrict__ logits, long total) {
+                                                        float* __restrict__ mask, float* __restrict__ logits, long total, long y_lo) {
     long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
     int w = (int)(i % W);
     long r = i / W;
     int h = (int)(r % H), b = (int)(r / H);
-    const _Float16* p = y + (((long)b * (H + 2 * PH) + h + PH) * (W + 2 * PW) + w + PW) * 32;
+    const long p = (((long)b * (H + 2 * PH) + h + PH) * (W + 2 * PW) + w + PW) * 32;
     float acc = bias;
 #pragma unroll
     for (int c8 = 0; c8 < 4; ++c8) {
-        f16x8 v = *(const f16x8*)(p + c8 * 8);
+        float v[8];
+        load_h_rt<8>(y, p + c8 * 8, y_lo, v);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc = fmaf((float)v[j], wgt[c8 * 8 + j], acc);
+        for (int j = 0; j < 8; ++j) acc = fmaf(v[j], wgt[c8 * 8 + j], acc);
     }
     if (logits) logits[i] = acc;
     mask[i] = 1.f / (1.f + expf(-acc));
@@ -90,29 +92,56 @@ __global__ __launch_bounds__(256) void unet_head_kernel(const _Float16* __restri
 
 using namespace advh;
 
-extern "C" int advh_unet_stem(const float* mag, int Fq, int Tq, int B, int H, int W, const float* wgt, const float* bias,
-                              void* out, int PH, int PW, float slope, advh_stream_t stream) {
+static int stem_launch(const float* mag, int Fq, int Tq, int B, int H, int W, const float* wgt, const float* bias,
+                       void* out, int64_t out_lo, int PH, int PW, float slope, advh_stream_t stream) {
     if (!mag || !wgt || !bias || !out || B <= 0 || H <= 0 || (H & 1) || W <= 0 || H > Fq || W > Tq || PH < 0 || PW < 0) return ADVH_EINVAL;
     long total = (long)B * (H / 2) * W;
     hipLaunchKernelGGL(unet_stem_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, mag, Fq, Tq, H, W,
-                       wgt, bias, (_Float16*)out, PH, PW, slope, total);
+                       wgt, bias, (_Float16*)out, PH, PW, slope, total, (long)out_lo);
     return ADVH_LAUNCH_CHECK();
 }
+extern "C" int advh_unet_stem(const float* mag, int Fq, int Tq, int B, int H, int W, const float* wgt, const float* bias,
+                              void* out, int PH, int PW, float slope, advh_stream_t stream) {
+    return stem_launch(mag, Fq, Tq, B, H, W, wgt, bias, out, 0, PH, PW, slope, stream);
+}
+extern "C" int advh_unet_stem_split(const float* mag, int Fq, int Tq, int B, int H, int W, const float* wgt, const float* bias,
+                                    void* out, int64_t out_lo, int PH, int PW, float slope, advh_stream_t stream) {
+    if (out_lo <= 0 || out_lo % 8) return ADVH_EINVAL;
+    return stem_launch(mag, Fq, Tq, B, H, W, wgt, bias, out, out_lo, PH, PW, slope, stream);
+}
 
-extern "C" int advh_unet_pack_x(const float* mag, int Fq, int Tq, int B, int H, int W, void* cat, int C, int c0, int PH, int PW,
-                                advh_stream_t stream) {
+static int pack_x_launch(const float* mag, int Fq, int Tq, int B, int H, int W, void* cat, int64_t cat_lo, int C, int c0, int PH, int PW,
+                         advh_stream_t stream) {
     if (!mag || !cat || B <= 0 || H <= 0 || W <= 0 || H > Fq || W > Tq || C % 8 || c0 % 8 || c0 + 8 > C) return ADVH_EINVAL;
     long total = (long)B * H * W;
     hipLaunchKernelGGL(unet_pack_x_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, mag, Fq, Tq, H, W,
-                       (_Float16*)cat, C, c0, PH, PW, total);
+                       (_Float16*)cat, C, c0, PH, PW, total, (long)cat_lo);
     return ADVH_LAUNCH_CHECK();
 }
+extern "C" int advh_unet_pack_x(const float* mag, int Fq, int Tq, int B, int H, int W, void* cat, int C, int c0, int PH, int PW,
+                                advh_stream_t stream) {
+    return pack_x_launch(mag, Fq, Tq, B, H, W, cat, 0, C, c0, PH, PW, stream);
+}
+extern "C" int advh_unet_pack_x_split(const float* mag, int Fq, int Tq, int B, int H, int W, void* cat, int64_t cat_lo, int C, int c0,
+                                      int PH, int PW, advh_stream_t stream) {
+    if (cat_lo <= 0 || cat_lo % 8) return ADVH_EINVAL;
+    return pack_x_launch(mag, Fq, Tq, B, H, W, cat, cat_lo, C, c0, PH, PW, stream);
+}
 
-extern "C" int advh_unet_head(const void* y, int B, int H, int W, int PH, int PW, const float* wgt, float bias, float* mask,
-                              float* logits, advh_stream_t stream) {
+static int head_launch(const void* y, int64_t y_lo, int B, int H, int W, int PH, int PW, const float* wgt, float bias, float* mask,
+                       float* logits, advh_stream_t stream) {
     if (!y || !wgt || !mask || B <= 0 || H <= 0 || W <= 0) return ADVH_EINVAL;
     long total = (long)B * H * W;
     hipLaunchKernelGGL(unet_head_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const _Float16*)y, H, W,
-                       PH, PW, wgt, bias, mask, logits, total);
+                       PH, PW, wgt, bias, mask, logits, total, (long)y_lo);
     return ADVH_LAUNCH_CHECK();
+}
+extern "C" int advh_unet_head(const void* y, int B, int H, int W, int PH, int PW, const float* wgt, float bias, float* mask,
+                              float* logits, advh_stream_t stream) {
+    return head_launch(y, 0, B, H, W, PH, PW, wgt, bias, mask, logits, stream);
+}
+extern "C" int advh_unet_head_split(const void* y, int64_t y_lo, int B, int H, int W, int PH, int PW, const float* wgt, float bias,
+                                    float* mask, float* logits, advh_stream_t stream) {
+    if (y_lo <= 0 || y_lo % 8) return ADVH_EINVAL;
+    return head_launch(y, y_lo, B, H, W, PH, PW, wgt, bias, mask, logits, stream);
 }
