@@ -2,7 +2,9 @@
 """Headline benchmark: explanations/sec on synthetic 16 kHz 4 s clips (BASELINE.json).
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+        N > 1 without a launcher: this script starts the N ranks itself (child processes through
+        `python -m torch.distributed.run`, before anything touches the GPU) and relays rank 0's JSON line;
+        under torchrun (WORLD_SIZE set) it is one of the ranks.
 
 A *step* is one pass of the whole hot path over one batch of 64 clips already resident in HBM:
 STFT -> wav2vec2-base embedder + logreg -> U-Net mask decoder -> masked ISTFT x2 -> embedder x2
@@ -11,14 +13,22 @@ batches (utterances shard with no data-path collective, "weak" scaling); the onl
 fixed-order gather of the per-clip probabilities for the LMAC metrics, done once inside the timed
 region.  Rank 0 prints ONE JSON line.
 
+Precision: the headline runs the fp32-class mode (`"dtype": "f32"`: split-format operands, three fp16 MFMAs per
+product, fp32 accumulate -- the arithmetic class of the fp32 reference; its matrix peak is 2.5 PFLOP/s / 3).  The
+fp16-operand mode is measured right after it and reported under `"f16"`.  `--precision f16` makes fp16 the headline.
+
 `roofline` is for the dominant kernel (the implicit-GEMM tile with the largest total time, csrc/gemm.hip): algorithmic
-FLOPs of its launches / their device time, measured with HIP events recorded on the launch stream
-inside the timed steps.  `cpu_baseline` times the CPU oracle (plain torch, the reference arithmetic)
-on a bounded sample of the same workload on this host's cores (rank 0, N = 1 only).
+FLOPs of its launches / their device time, measured with HIP events recorded on the launch stream inside the timed
+steps.  `cpu_baseline` times the CPU oracle (plain torch, the reference arithmetic) on a bounded sample of the same
+workload on this host's cores (rank 0, N = 1 only).  The default N = 1 invocation also measures BASELINE config 3
+(`"hifigan"`: HiFi-GAN V1, 256 x 251 mel frames) and config 5's per-GPU share (`"ig"`: IntegratedGradients, 50 steps x
+16 clips, wav2vec2-large) and appends them as extra keys; `--workload hifigan|ig` runs one of them as the headline.
 """
 import argparse
 import json
 import os
+import statistics
+import subprocess
 import sys
 import time
 
@@ -26,36 +36,86 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "xai-audio-deepfakes_amd"))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-
 BATCH = 64
 AUDIO_LENGTH = 4
 MFMA_F16_PEAK_TFLOPS = 2500.0        # MI355X dense fp16/bf16 MFMA peak (MI355X_MICROARCH.md)
+PEAK = {"f16": MFMA_F16_PEAK_TFLOPS, "f32": MFMA_F16_PEAK_TFLOPS / 3.0}     # fp32-class: 3 fp16 MFMAs per product
+PEAK_NOTE = {"f16": "dense fp16 MFMA peak", "f32": "dense fp16 MFMA peak / 3: the fp32-class mode issues three fp16 MFMAs per product "
+             "(the native fp32 MFMA peak is 157 TFLOP/s)"}
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--workload", choices=("explain", "hifigan", "ig"), default="explain")
+    ap.add_argument("--precision", choices=("f32", "f16"), default="f32", help="headline precision of the explain workload")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (f16 / hifigan / ig keys)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verbose", action="store_true")
     ap.add_argument("--streams", type=int, default=1, help="HIP streams the 3B embedder batch is split over")
     ap.add_argument("--rehearse", action="store_true",
-                    help="multi-rank dry run on ONE GPU: gloo backend, every rank on cuda:0 (checks the sharding / "
+                    help="multi-rank dry run on ONE GPU: gloo backend, every rank on cuda:0 (checks the launch / sharding / "
                          "gather / timing logic where no multi-GPU node is available; not a measurement)")
     ap.add_argument("--tune", action="store_true",
                     help="time every candidate GEMM tile per launch first and keep the fastest (default: the 128x128 tile)")
     ap.add_argument("--no-tune", action="store_true", help=argparse.SUPPRESS)       # kept for old command lines
-    ap.add_argument("--cpu-clips", type=int, default=32)
-    ap.add_argument("--cpu-threads", type=int, default=16, help="host threads for the CPU baseline (a 1-GPU box owns 16)")
-    args = ap.parse_args()
+    ap.add_argument("--cpu-clips", type=int, default=64)
+    ap.add_argument("--cpu-repeats", type=int, default=3)
+    ap.add_argument("--cpu-threads", type=int, default=0, help="host threads for the CPU baseline (0 = every core this process may use)")
+    ap.add_argument("--master-port", type=int, default=0)
+    return ap.parse_args()
 
+
+def spawn_ranks(args) -> int:
+    """`bench.py --gpus N` without a launcher: start the N ranks as CHILD processes (never exec: this process stays the
+    parent and has not touched the GPU) and relay their output; rank 0 prints the JSON line."""
+    port = args.master_port or (29500 + os.getpid() % 20000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def usable_cpus() -> int:
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    try:                                                   # cgroup v2 quota of the box ("max 100000" = unlimited)
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = max(1, min(n, int(int(q) / int(per))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
+
+    import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
@@ -67,18 +127,34 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo" if args.rehearse else "nccl", rank=rank, world_size=world)   # "nccl" = RCCL on ROCm
-
-    from addvisor_hip import gemm as G, pipeline as P, synthetic as syn
     torch.set_grad_enabled(False)
+    ctx = dict(args=args, dev=dev, rank=rank, world=world, dist=dist)
 
+    if args.workload == "hifigan":
+        line = hifigan_line(ctx, bench_hifigan(ctx, args.batch if args.batch != BATCH else 256, args.steps, args.warmup))
+    elif args.workload == "ig":
+        line = ig_line(ctx, bench_ig(ctx, 16, 64))
+    else:
+        line = explain_line(ctx)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------ the explanation step
+def run_explain(ctx, precision, steps, warmup):
+    """Time `steps` explanation steps in one precision; returns the numbers of that run."""
+    import torch
+    from addvisor_hip import gemm as G, pipeline as P, synthetic as syn
+    args, dev, rank, world, dist = ctx["args"], ctx["dev"], ctx["rank"], ctx["world"], ctx["dist"]
     cfg = syn.base_config()
     emb_sd = syn.embedder_weights(cfg)
     coef, icpt = syn.logreg_weights(cfg.hidden_size)
     unet_sd = syn.unet_weights()
-    pipe = P.ExplainPipeline(cfg, emb_sd, coef, icpt, unet_sd, dev, audio_length=AUDIO_LENGTH, streams=args.streams)
-
+    pipe = P.ExplainPipeline(cfg, emb_sd, coef, icpt, unet_sd, dev, audio_length=AUDIO_LENGTH, streams=args.streams, precision=precision)
     B, L = args.batch, AUDIO_LENGTH * 16000
-    n_batches = max(1, min(args.steps, 8))
+    n_batches = max(1, min(steps, 8))
     # clip indices are global and disjoint per rank: rank r, batch j -> clips [(j*world + r)*B, ...)
     batches = [syn.make_clips(B, L, first=(j * world + rank) * B).to(dev) for j in range(n_batches)]
 
@@ -92,14 +168,14 @@ def main():
         if args.verbose and rank == 0:
             for rec in G.TUNER.log:
                 print("tuned", rec, file=sys.stderr)
-    for i in range(args.warmup):
+    for i in range(warmup):
         pipe.explain(batches[i % n_batches])
     barrier()
 
     G.PROFILE.reset(enabled=os.environ.get("ADDVISOR_BENCH_NO_EVENTS", "0") == "0")     # 1: measure the cost of the per-launch events
     probs = []
     t0 = time.perf_counter()
-    for i in range(args.steps):
+    for i in range(steps):
         out = pipe.explain(batches[i % n_batches])
         probs.append(torch.cat([out["predictions"], out["theta_out"], out["masked_predictions"]], 1))
     local = torch.cat(probs, 0)
@@ -115,65 +191,184 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    res = dict(precision=precision, elapsed=elapsed, steps=steps, value=world * B * steps / elapsed, metrics=metrics,
+               flops_step=pipe.flops(B), roofline=gemm_roofline(G, precision, args.tune), cfg=cfg, weights=(emb_sd, coef, icpt, unet_sd))
+    del pipe, batches
+    torch.cuda.empty_cache()
+    return res
 
-    n_expl = world * B * args.steps
-    value = n_expl / elapsed
-    gemm_ms, gemm_flops, gemm_n = G.PROFILE.summary()                      # the tile with the largest total time
-    gemm_kernel = getattr(G.PROFILE, "kernel", "gemm_f16_kernel")         # the instantiation rocprofv3 lists under this name
-    achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else None
-    flops_step = pipe.flops(B)
 
-    cpu = None
+def gemm_roofline(G, precision, tuned=False):
+    ms, flops, n = G.PROFILE.summary()                                     # the tile instantiation with the largest total time
+    kernel = getattr(G.PROFILE, "kernel", "gemm_f16_kernel")              # ... under the name rocprofv3 lists it
+    achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else None
+    peak = PEAK[precision]
+    traffic, source = committed_traffic(kernel) if not tuned else (None, None)
+    return {"kernel": kernel + (" (tuned tile choice)" if tuned else ""), "bound": "mfma",
+            "achieved": None if achieved is None else round(achieved, 1), "peak": round(peak, 1), "peak_note": PEAK_NOTE[precision],
+            "unit": "TFLOP/s", "frac": None if achieved is None else round(achieved / peak, 4),
+            "traffic": traffic, "traffic_source": source, "launches": n,
+            "avg_launch_us": None if not n else round(1e3 * ms / n, 2),
+            "gflop_per_launch": None if not n else round(flops / n / 1e9, 2)}
+
+
+def committed_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE collected in
+    separate runs of this same command, tools/pmc_bench_traffic.sh).  PMC counters cannot be read from inside an unprofiled
+    run, so this is NOT a measurement of the present run: the source file is named next to the number, else null."""
+    for name in ("r02_gemm_traffic.json", "r01_gemm_traffic.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            with open(path) as fh:
+                for k, v in json.load(fh).items():
+                    if kernel in k:
+                        return round(v["hbm_bytes_per_launch"]), (f"profiles/{name}: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                                                  "command (FETCH_SIZE x2 per MI355X_MICROARCH.md), bytes per launch; not re-measured in this run")
+    return None, None
+
+
+def explain_line(ctx):
+    args, rank, world = ctx["args"], ctx["rank"], ctx["world"]
+    head = run_explain(ctx, args.precision, args.steps, args.warmup)
+    B, L = args.batch, AUDIO_LENGTH * 16000
+    prec_txt = {"f32": "fp32-class: split-format (hi + lo * 2^-11) operands, 3 fp16 MFMAs per product, fp32 accumulate / norms / residual",
+                "f16": "fp16 operands, fp32 accumulate / norms / residual"}
+    line = {
+        "metric": "explanations/sec (16 kHz, 4 s clips)", "value": round(head["value"], 2), "unit": "explanations/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * head["elapsed"] / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+        "config": {"workload": "BASELINE config 2 extended to the full explanation: batch 64 x 4 s clips, "
+                               "STFT + wav2vec2-base embedder (to hidden layer 9) + logreg + U-Net mask decoder "
+                               "+ masked ISTFT x2 + embedder re-forward x2 + LMAC metrics",
+                   "batch_per_gpu": B, "clip_samples": L, "embedder": "wav2vec2-base (seeded random weights)",
+                   "precision": prec_txt[args.precision], "sharding": f"utterance x{world}",
+                   "gflop_per_explanation": round(head["flops_step"] / B / 1e9, 1)},
+        "lmac": {k: round(v, 6) for k, v in head["metrics"].items()},
+        "pipeline_tflops": round(head["flops_step"] * args.steps * world / head["elapsed"] / 1e12, 1),
+        "roofline": head["roofline"],
+        "cpu_baseline": None,
+    }
+    extras = world == 1 and not args.no_extras and not args.tune
+    if extras:
+        other = "f16" if args.precision == "f32" else "f32"
+        o = run_explain(ctx, other, args.steps, args.warmup)
+        line[other] = {"value": round(o["value"], 2), "unit": "explanations/s", "ms_per_step": round(1e3 * o["elapsed"] / args.steps, 3),
+                       "precision": prec_txt[other], "lmac": {k: round(v, 6) for k, v in o["metrics"].items()},
+                       "pipeline_tflops": round(o["flops_step"] * args.steps / o["elapsed"] / 1e12, 1), "roofline": o["roofline"]}
+        line["hifigan"] = bench_hifigan(ctx, 256, 5, 1)
+        line["ig"] = bench_ig(ctx, 16, 64)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(cfg, emb_sd, coef, icpt, unet_sd, args.cpu_clips, L, args.cpu_threads)
-
-    traffic = None                       # HBM bytes per launch of the dominant kernel, from the committed PMC passes
-    tpath = os.path.join(ROOT, "profiles", "r01_gemm_traffic.json")
-    if os.path.exists(tpath) and not args.tune:
-        with open(tpath) as fh:
-            for k, v in json.load(fh).items():
-                if gemm_kernel in k:
-                    traffic = round(v["hbm_bytes_per_launch"])
-    if rank == 0:
-        line = {
-            "metric": "explanations/sec (16 kHz, 4 s clips)", "value": round(value, 2), "unit": "explanations/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": "BASELINE config 2 extended to the full explanation: batch 64 x 4 s clips, "
-                                   "STFT + wav2vec2-base embedder (to hidden layer 9) + logreg + U-Net mask decoder "
-                                   "+ masked ISTFT x2 + embedder re-forward x2 + LMAC metrics",
-                       "batch_per_gpu": B, "clip_samples": L, "embedder": "wav2vec2-base (seeded random weights)",
-                       "precision": "fp16 operands, fp32 accumulate / norms / residual", "sharding": f"utterance x{world}",
-                       "gflop_per_explanation": round(flops_step / B / 1e9, 1)},
-            "lmac": {k: round(v, 6) for k, v in metrics.items()},
-            "pipeline_tflops": round(flops_step * args.steps * world / elapsed / 1e12, 1),
-            "roofline": {"kernel": gemm_kernel + (" (tuned tile choice)" if args.tune else ""), "bound": "mfma",
-                         "achieved": None if achieved is None else round(achieved, 1), "peak": MFMA_F16_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": None if achieved is None else round(achieved / MFMA_F16_PEAK_TFLOPS, 4),
-                         "traffic": traffic, "traffic_source": "profiles/r01_gemm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
-                         "FETCH_SIZE x2 per MI355X_MICROARCH.md; bytes per launch)" if traffic else None, "launches": gemm_n,
-                         "avg_launch_us": None if not gemm_n else round(1e3 * gemm_ms / gemm_n, 2),
-                         "gflop_per_launch": None if not gemm_n else round(gemm_flops / gemm_n / 1e9, 2)},
-            "cpu_baseline": cpu,
-        }
-        print(json.dumps(line), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+        cfg = head["cfg"]
+        emb_sd, coef, icpt, unet_sd = head["weights"]
+        line["cpu_baseline"] = cpu_baseline(cfg, emb_sd, coef, icpt, unet_sd, args.cpu_clips, L, args.cpu_threads, args.cpu_repeats)
+    return line
 
 
-def cpu_baseline(cfg, emb_sd, coef, icpt, unet_sd, n_clips, L, threads):
-    """The CPU oracle (plain torch = the reference arithmetic) on a bounded sample, this host's cores."""
+# ------------------------------------------------------------------------------------------ BASELINE config 3
+def bench_hifigan(ctx, B, steps, warmup):
+    """HiFi-GAN V1 vocoder, B x 251 mel frames (4 s) -> waveform; fp16 operands (the fp32-class mode covers the explanation
+    path; the vocoder's stated tolerance is on waveforms)."""
+    import torch
+    from addvisor_hip import gemm as G, synthetic as syn
+    from addvisor_hip.hifigan import HipHifigan
+    dev = ctx["dev"]
+    T = 251
+    cfg = syn.HifiganConfig()
+    net = HipHifigan(cfg, syn.hifigan_weights(cfg), dev)
+    g = torch.Generator().manual_seed(7)
+    mel = (torch.randn(B, 80, T, generator=g) * 2 - 4).to(dev)
+    for _ in range(max(1, warmup)):
+        net.decode_batch(mel)
+    torch.cuda.synchronize()
+    G.PROFILE.reset(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        wav = net.decode_batch(mel)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    G.PROFILE.enabled = False
+    fl = net.flops(B, T)
+    out = {"workload": f"BASELINE config 3: HiFi-GAN V1 decode_batch, {B} x {T} mel frames (4 s), one GPU", "value": round(B / dt, 1),
+           "unit": "clips/s", "ms_per_batch": round(dt * 1e3, 2), "steps": steps, "dtype": "f16",
+           "gflop_per_clip": round(fl / B / 1e9, 1), "tflops": round(fl / dt / 1e12, 1), "finite": bool(torch.isfinite(wav).all().item()),
+           "roofline": gemm_roofline(G, "f16")}
+    del net, mel, wav
+    torch.cuda.empty_cache()
+    return out
+
+
+def hifigan_line(ctx, r):
+    args, world = ctx["args"], ctx["world"]
+    return {"metric": "HiFi-GAN V1 vocoder clips/sec (4 s, 251 mel frames)", "value": round(r["value"] * world, 1), "unit": "clips/s", "n_gpus": world,
+            "steps": r["steps"], "warmup": args.warmup, "ms_per_step": r["ms_per_batch"], "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f16", "data": "synthetic", "config": {"workload": r["workload"]}, "roofline": r["roofline"],
+            "tflops": r["tflops"], "cpu_baseline": None}
+
+
+# ------------------------------------------------------------------------------------------ BASELINE config 5
+def bench_ig(ctx, B, chunk):
+    """IntegratedGradients, n_steps = 50, wav2vec2-large, B clips = one GPU's share of config 5's batch of 128 over 8 GPUs;
+    path-batched forward + dgrad-only backward on the fp16 kernels."""
+    import torch
+    from addvisor_hip import gemm as G, synthetic as syn
+    from addvisor_hip.attribution import HipAttribution
+    from addvisor_hip.embedder import HipEmbedder
+    dev = ctx["dev"]
+    cfg = syn.large_config()
+    sd = syn.embedder_weights(cfg)
+    coef, icpt = syn.logreg_weights(cfg.hidden_size)
+    att = HipAttribution(HipEmbedder(cfg, sd, coef, icpt, dev, precision="f16"))
+    w = syn.make_clips(B, 64000).to(dev)
+    att.integrated_gradients(w, n_steps=max(1, chunk // B), internal_batch_size=chunk)      # warm-up: builds the one chunk-shaped workspace
+    torch.cuda.synchronize()
+    G.PROFILE.reset(True)
+    t0 = time.perf_counter()
+    attr = att.integrated_gradients(w, n_steps=50, internal_batch_size=chunk)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    G.PROFILE.enabled = False
+    rows = min(chunk, 50 * B) // B * B if chunk >= B else B
+    fwd = att.emb.flops(rows, 64000) / rows
+    out = {"workload": f"BASELINE config 5, one GPU's share: IntegratedGradients n_steps=50, wav2vec2-large, {B} clips x 4 s, internal batch {chunk}",
+           "value": round(50 * B / dt, 1), "unit": "path points/s", "clips_per_s": round(B / dt, 3), "seconds": round(dt, 3), "dtype": "f16",
+           "fwd_gflop_per_point": round(fwd / 1e9, 1), "approx_tflops_fwd_plus_dgrad": round(2 * fwd * 50 * B / dt / 1e12, 1),
+           "finite": bool(torch.isfinite(attr).all().item()), "roofline": gemm_roofline(G, "f16")}
+    del att, attr, w
+    torch.cuda.empty_cache()
+    return out
+
+
+def ig_line(ctx, r):
+    args, world = ctx["args"], ctx["world"]
+    return {"metric": "IntegratedGradients path points/sec (50 steps, wav2vec2-large, 4 s clips)", "value": round(r["value"] * world, 1),
+            "unit": "path points/s", "n_gpus": world, "steps": 1, "warmup": 1, "ms_per_step": round(1e3 * r["seconds"], 1), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic", "config": {"workload": r["workload"]},
+            "roofline": r["roofline"], "cpu_baseline": None}
+
+
+# ------------------------------------------------------------------------------------------ CPU baseline
+def cpu_baseline(cfg, emb_sd, coef, icpt, unet_sd, n_clips, L, threads, repeats):
+    """The CPU oracle (plain torch = the reference arithmetic) on a bounded sample of the same workload on this host's
+    cores: `n_clips` clips in chunks of 16, `repeats` repetitions, median."""
+    import torch
     from addvisor_hip import synthetic as syn
     from oracle import lmac_ref
-    torch.set_num_threads(max(1, min(threads, os.cpu_count() or 1)))
+    nthreads = threads if threads > 0 else usable_cpus()
+    torch.set_num_threads(max(1, nthreads))
     w = syn.make_clips(n_clips, L)
-    t0 = time.perf_counter()
+    times = []
     with torch.no_grad():
-        lmac_ref.explain(w, emb_sd, cfg, coef, icpt, unet_sd, audio_length=AUDIO_LENGTH)
-    dt = time.perf_counter() - t0
+        for _ in range(max(1, repeats)):
+            t0 = time.perf_counter()
+            for i in range(0, n_clips, 16):
+                lmac_ref.explain(w[i:i + 16], emb_sd, cfg, coef, icpt, unet_sd, audio_length=AUDIO_LENGTH)
+            times.append(time.perf_counter() - t0)
+    dt = statistics.median(times)
     return {"value": round(n_clips / dt, 3), "unit": "explanations/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n_clips} clips of the same workload through oracle/lmac_ref.explain (plain torch fp32), {dt:.1f} s"}
+            "cpu": cpu_model(), "host_logical_cpus": os.cpu_count(),
+            "sample": f"{n_clips} clips of the same workload through oracle/lmac_ref.explain (plain torch fp32) in chunks of 16, "
+                      f"{len(times)} repetitions, median {dt:.1f} s (all: {', '.join(f'{t:.1f}' for t in times)} s)"}
 
 
 if __name__ == "__main__":

@@ -298,6 +298,14 @@ int advh_lmac_metrics_accumulate(const float* predictions, const float* theta_ou
  * advh_hifigan_conv_post: Conv1d(C,1,k,"same") + tanh -> wav [B][1][T] fp32; w is [k][C] fp32.
  * advh_mel_log          : out [B][n_mels][T] = log(clamp(fb^T |X|, 1e-5)), fb [F][n_mels], mag [B][F][T].     */
 int advh_hifigan_pack_mel(const float* mel, void* out, int B, int C, int T, int halo, advh_stream_t stream);
+/* Fidelity options of the SpeechBrain wrapper behind hifigan.py:106-110, 180 (not verifiable offline, hence options):
+ * advh_hifigan_pack_mel_pad : as pack_mel with `pad` replicated frames on both sides (the generator's `inference_padding`:
+ *                             F.pad(mel, (pad, pad), "replicate")); the map holds T + 2*pad interior rows.
+ * advh_halo_fill_f16        : fill the halo of a channels-last fp16 map [B][T+2*halo][C] with zeros (mode 0) or with the
+ *                             reflection of the interior about its first / last sample (mode 1: torch "reflect" padding, the
+ *                             default padding_mode of SpeechBrain's Conv1d), so "same" convolutions read it in place.      */
+int advh_hifigan_pack_mel_pad(const float* mel, void* out, int B, int C, int T, int pad, int halo, advh_stream_t stream);
+int advh_halo_fill_f16(void* x, int B, int T, int C, int halo, int mode, advh_stream_t stream);
 int advh_hifigan_mrf_mix(const void* a, const void* b, const void* c, void* y, float slope, int64_t numel, advh_stream_t stream);
 int advh_hifigan_conv_post(const void* x, const float* w, float bias, float* wav, int B, int C, int T, int halo, int k,
                            advh_stream_t stream);

@@ -31,8 +31,11 @@ def resblock1(x, sd, p, dilations, slope, padding_mode):
     return x
 
 
-def generator(mel: torch.Tensor, sd, cfg, padding_mode: str = "zeros") -> torch.Tensor:
-    """``mel [B, 80, T] -> wav [B, 1, T*256]``."""
+def generator(mel: torch.Tensor, sd, cfg, padding_mode: str = "zeros", inference_padding: int = 0) -> torch.Tensor:
+    """``mel [B, 80, T] -> wav [B, 1, (T + 2 * inference_padding) * 256]``.  ``inference_padding``: frames replicated on both
+    sides first (``F.pad(c, (p, p), "replicate")`` of the SpeechBrain / Coqui generator's ``inference``)."""
+    if inference_padding:
+        mel = F.pad(mel, (inference_padding, inference_padding), mode="replicate")
     x = _conv1d(mel, sd["conv_pre.weight"], sd["conv_pre.bias"], 1, padding_mode)
     nk = len(cfg.resblock_kernel_sizes)
     for i, (r, k) in enumerate(zip(cfg.upsample_rates, cfg.upsample_kernel_sizes)):

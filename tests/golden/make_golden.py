@@ -205,6 +205,7 @@ def main():
 
     # ---- 7. the five LMAC metric formulas (LMAC_metrics.py:31-73) on a 64-triple table incl. ties at 0.5
     part_lmac_metrics()
+    part_large()
 
 
 def part_lmac_metrics():
@@ -218,7 +219,24 @@ def part_lmac_metrics():
          **per)
 
 
-PARTS = {"lmac_metrics": part_lmac_metrics}
+def part_large():
+    """Full-size wav2vec2-LARGE (layer-norm feature extractor, pre-LN encoder; BASELINE config 5's embedder), one 4 s clip
+    through the reference's own extract_features: moments, a corner and the pooled vector of hidden_states[9], plus the
+    per-layer moments of hidden_states[0..9] from the HF model the reference calls (SURVEY.md §8(c) fixture (ii))."""
+    large = syn.large_config()
+    ce, apm, adv, lf = import_reference(large)
+    m = build_hf(large)
+    apm.wav2vec2 = m
+    w = syn.make_clips(1, 64000)
+    f = apm.AudioProcessor(audio_length=4).extract_features(w)          # [199, 1024]
+    hs = m(ce.zero_mean_unit_var_norm(w), output_hidden_states=True).hidden_states
+    save("embedder_large_4s.npz", shape=np.array(f.shape), mean=f.double().mean(), absmax=f.abs().max(), std=f.double().std(),
+         corner=f[:8, :16], pooled=f.mean(0),
+         layer_mean=np.array([h.double().mean().item() for h in hs[:10]]), layer_std=np.array([h.double().std().item() for h in hs[:10]]),
+         layer_absmax=np.array([h.abs().max().item() for h in hs[:10]]))
+
+
+PARTS = {"lmac_metrics": part_lmac_metrics, "large": part_large}
 
 
 if __name__ == "__main__":

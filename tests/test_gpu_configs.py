@@ -1,0 +1,140 @@
+"""GPU parity at the sizes BASELINE.json's configs 3, 4 and 5 name (the small-shape parity lives in the per-kernel test files).
+
+  config 3  HiFi-GAN V1 on 251 mel frames (4 s): B = 2 against the oracle, B = 256 through size-independent properties
+            (finite, |wav| <= 1, batch invariance bit-exact, run-to-run determinism); reference call: hifigan.py:180.
+  config 4  run_addvisor_metrics (LMAC_metrics.py:117-172) over ragged batches of 4 s clips, wav2vec2-base.
+  config 5  wav2vec2-LARGE (1024 / 16 heads / 4096, layer-norm feature extractor, pre-LN encoder) forward in both precisions
+            against the oracle and the reference-generated fixture; IntegratedGradients n_steps = 50 (captum_saliency.py:131-135)
+            on that model against the oracle, path-batched with a small internal batch.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from addvisor_hip import runtime, synthetic as syn
+from addvisor_hip.embedder import HipEmbedder
+from addvisor_hip.hifigan import HipHifigan
+from oracle import attribution_ref, hifigan_ref, lmac_ref, wav2vec2_ref
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+
+
+# ------------------------------------------------------------------------------------------ config 3
+def _mel(B, T, seed):
+    r = np.random.Generator(np.random.PCG64(seed))
+    return torch.from_numpy(r.normal(-4.0, 2.0, size=(B, 80, T)).astype(np.float32))
+
+
+def test_hifigan_v1_251_frames_vs_oracle(gpu_device):
+    """Stated tolerance (fp16 operands, fp32 accumulate, waveform in [-1, 1]): max 2e-2, mean 2e-3."""
+    cfg = syn.HifiganConfig()
+    sd = syn.hifigan_weights(cfg)
+    mel = _mel(2, 251, 11)
+    wav = HipHifigan(cfg, sd, gpu_device).decode_batch(mel.to(gpu_device))
+    ref = hifigan_ref.generator(mel, sd, cfg)
+    assert wav.shape == ref.shape == (2, 1, 251 * 256)
+    err = (wav.cpu() - ref).abs()
+    print(f"HiFi-GAN V1 2 x 251 frames: max err {err.max():.3e} mean {err.mean():.3e} |ref|max {ref.abs().max():.3f}")
+    assert err.max().item() <= 2e-2 and err.mean().item() <= 2e-3
+
+
+def test_hifigan_v1_batch256_properties(gpu_device):
+    cfg = syn.HifiganConfig()
+    sd = syn.hifigan_weights(cfg)
+    net = HipHifigan(cfg, sd, gpu_device)
+    mel = _mel(256, 251, 12).to(gpu_device)
+    wav = net.decode_batch(mel)
+    assert wav.shape == (256, 1, 251 * 256)
+    assert bool(torch.isfinite(wav).all()) and wav.abs().max().item() <= 1.0
+    assert wav.std().item() > 1e-4                                          # not a constant
+    again = net.decode_batch(mel)
+    assert torch.equal(again, wav)                                          # deterministic
+    pair = net.decode_batch(mel[[0, 255]].contiguous())                    # utterances are independent => sharding is exact
+    assert torch.equal(pair[0], wav[0]) and torch.equal(pair[1], wav[255])
+
+
+# ------------------------------------------------------------------------------------------ config 5
+@pytest.fixture(scope="module")
+def large_model():
+    cfg = syn.large_config()
+    sd = syn.embedder_weights(cfg)
+    coef, icpt = syn.logreg_weights(cfg.hidden_size)
+    return cfg, sd, coef, icpt
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16"])
+def test_large_embedder_4s(gpu_device, golden, large_model, precision):
+    """hidden_states[9] of a pre-LN encoder is the un-normalised residual stream, so the tolerance is relative to its
+    magnitude: f32 mode 2e-5 * max|ref| (+1e-5), f16 mode 4e-3 * max|ref| (mean 4e-4 * max|ref|); logits 1e-4 / 1e-2."""
+    cfg, sd, coef, icpt = large_model
+    w = syn.make_clips(1, 64000)
+    emb = HipEmbedder(cfg, sd, coef, icpt, gpu_device, precision=precision)
+    hid, logit, prob = emb.forward(w.to(gpu_device))
+    ref_h = wav2vec2_ref.hidden_states(wav2vec2_ref.zero_mean_unit_var_norm(w), sd, cfg, upto=9)[9]
+    ref_logit, _ = wav2vec2_ref.logreg(ref_h.mean(1), coef, icpt)
+    amax = ref_h.abs().max().item()
+    err = (hid.cpu() - ref_h).abs()
+    le = (logit.cpu() - ref_logit).abs().max().item()
+    print(f"wav2vec2-large {precision}: hidden max err {err.max():.3e} mean {err.mean():.3e}, |ref|max {amax:.2f}, logit err {le:.3e}")
+    tol_max, tol_mean, tol_logit = (2e-5 * amax + 1e-5, 2e-6 * amax + 1e-6, 1e-4) if precision == "f32" else (4e-3 * amax, 4e-4 * amax, 1e-2)
+    assert err.max().item() <= tol_max and err.mean().item() <= tol_mean and le <= tol_logit
+    g = golden("embedder_large_4s.npz")                                    # the reference's own extract_features
+    assert tuple(hid.shape[1:]) == tuple(g["shape"])
+    assert (hid[0, :8, :16].cpu() - torch.from_numpy(g["corner"])).abs().max().item() <= tol_max
+    assert (hid[0].mean(0).cpu() - torch.from_numpy(g["pooled"])).abs().max().item() <= tol_max
+
+
+def test_ig_50_steps_large(gpu_device, large_model):
+    """captum_saliency.py:131-135 at config 5's model and step count: IntegratedGradients(n_steps=50, gausslegendre, zero
+    baseline), 2 clips x 1 s, path-batched in chunks of 20 rows (10 steps), against the oracle (torch autograd through the
+    CPU restatement; parity unpinned: captum absent).  Stated tolerance (fp16 gradient chain): 3e-2 of max|attr|."""
+    from addvisor_hip.attribution import HipAttribution
+    cfg, sd, coef, icpt = large_model
+    att = HipAttribution(HipEmbedder(cfg, sd, coef, icpt, gpu_device))
+    w = syn.make_clips(2, 16000, seed=12)
+    ours = att.integrated_gradients(w.to(gpu_device), n_steps=50, internal_batch_size=20)
+    with torch.enable_grad():
+        ref = attribution_ref.integrated_gradients(w, sd, cfg, coef, icpt, n_steps=50)
+    rel = ((ours.cpu() - ref).abs().max() / ref.abs().max()).item()
+    cos = torch.nn.functional.cosine_similarity(ours.cpu().flatten(), ref.flatten(), dim=0).item()
+    print(f"IG 50 steps, wav2vec2-large: max rel err {rel:.3e}, cosine {cos:.6f}")
+    assert bool(torch.isfinite(ours).all()) and rel < 3e-2 and cos > 0.999
+    whole = att.integrated_gradients(w.to(gpu_device), n_steps=50, internal_batch_size=100)    # chunking does not change the sum order per clip
+    assert ((whole - ours).abs().max() / ref.abs().max()).item() < 1e-3
+
+
+# ------------------------------------------------------------------------------------------ config 4
+def test_run_addvisor_metrics_ragged_batches_4s(gpu_device, capsys):
+    """The dataset loop of LMAC_metrics.py:117-172 with the drop-in modules: 11 clips of 4 s, batch_size 4 => batches of
+    4, 4 and 3 (ragged tail), wav2vec2-base; the five printed means against the oracle run over the same clips in one batch."""
+    os.environ["ADDVISOR_EMBEDDER"] = "base"
+    runtime.reset()
+    try:
+        import LMAC_metrics
+        LMAC_metrics.audio_processor.audio_length = 4
+        clips = syn.make_clips(11, 64000, seed=93)
+
+        class DS(torch.utils.data.Dataset):
+            def __len__(self):
+                return 11
+
+            def __getitem__(self, i):
+                return clips[i].to(gpu_device), f"clip{i}.wav"
+
+        m = LMAC_metrics.run_addvisor_metrics("", "", batch_size=4, dataset=DS())
+        printed = capsys.readouterr().out.strip().splitlines()
+        assert [l.split(":")[0].strip() for l in printed] == ["faithfulness", "fidelity", "average drop", "average increase", "average gain"]
+        cfg, sd = runtime.embedder_config_and_weights()
+        clf = runtime.classifier()
+        ref = lmac_ref.explain(clips, sd, cfg, clf.coef_, clf.intercept_, syn.unet_weights(), audio_length=4)
+        r = lmac_ref.lmac_summary(ref["predictions"], ref["theta_out"], ref["masked_predictions"])
+        print("HIP", m, "oracle", r)
+        assert abs(m["faithfulness"] - r["faithfulness"]) < 1e-3 and abs(m["fidelity"] - r["fidelity"]) < 1e-6
+        assert abs(m["AD"] - r["AD"]) < 0.2 and abs(m["AI"] - r["AI"]) < 1e-3 and abs(m["AG"] - r["AG"]) < 0.2
+    finally:
+        LMAC_metrics.audio_processor.audio_length = 5
+        os.environ.pop("ADDVISOR_EMBEDDER", None)
+        runtime.reset()

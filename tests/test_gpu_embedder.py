@@ -21,7 +21,7 @@ TOL_HID_MAX, TOL_HID_MEAN, TOL_LOGIT = 3e-2, 3e-3, 1e-2
 def run_case(cfg, waves, dev, length=None):
     sd = syn.embedder_weights(cfg)
     coef, icpt = syn.logreg_weights(cfg.hidden_size)
-    emb = HipEmbedder(cfg, sd, coef, icpt, dev)
+    emb = HipEmbedder(cfg, sd, coef, icpt, dev, precision="f16")
     hid, logit, prob = emb.forward(waves.to(dev), length)
     w = waves if length is None else torch.nn.functional.pad(waves, (0, max(0, length - waves.shape[1])))[:, :length]
     x = wav2vec2_ref.zero_mean_unit_var_norm(w)
@@ -73,7 +73,7 @@ def test_batch_invariance(gpu_device):
     cfg = syn.tiny_config(False)
     sd = syn.embedder_weights(cfg)
     coef, icpt = syn.logreg_weights(cfg.hidden_size)
-    emb = HipEmbedder(cfg, sd, coef, icpt, gpu_device)
+    emb = HipEmbedder(cfg, sd, coef, icpt, gpu_device, precision="f16")
     w = syn.make_clips(5, 16000, seed=8).to(gpu_device)
     h5, l5, _ = emb.forward(w)
     h2, l2, _ = emb.forward(w[1:3].contiguous())

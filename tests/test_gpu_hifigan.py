@@ -49,3 +49,26 @@ def test_mel_front_end(gpu_device):
     mel = ops.mel_spectrogram(w.to(gpu_device))
     assert mel.shape == ref.shape == (2, 80, 63)
     assert (mel.cpu() - ref).abs().max().item() < 2e-3
+
+
+@pytest.mark.parametrize("padding_mode,inference_padding", [("reflect", 0), ("zeros", 5), ("reflect", 5)])
+def test_speechbrain_wrapper_options(gpu_device, padding_mode, inference_padding):
+    """The two wrapper choices that cannot be verified offline (hifigan.py:106-110: SpeechBrain's Conv1d defaults to
+    padding_mode="reflect"; its generator's inference() replicates `inference_padding` mel frames on both sides) as options
+    of the HIP generator, each against the oracle run with the same option; zeros / 0 stay the defaults."""
+    cfg = syn.HifiganConfig()
+    sd = syn.hifigan_weights(cfg)
+    r = np.random.Generator(np.random.PCG64(5))
+    mel = torch.from_numpy(r.normal(-4.0, 2.0, size=(2, cfg.in_channels, 40)).astype(np.float32))
+    net = HipHifigan(cfg, sd, gpu_device, padding_mode=padding_mode, inference_padding=inference_padding)
+    wav = net.decode_batch(mel.to(gpu_device))
+    ref = hifigan_ref.generator(mel, sd, cfg, padding_mode=padding_mode, inference_padding=inference_padding)
+    assert wav.shape == ref.shape == (2, 1, (40 + 2 * inference_padding) * cfg.hop)
+    err = (wav.cpu() - ref).abs()
+    plain = hifigan_ref.generator(mel, sd, cfg)
+    edge = (ref[..., : plain.shape[-1]] - plain).abs().max().item() if inference_padding == 0 else float("nan")
+    print(f"hifigan {padding_mode} / inference_padding {inference_padding}: max err {err.max():.3e} mean {err.mean():.3e}; "
+          f"option vs published model at the edges: {edge:.3e}")
+    assert err.max().item() <= TOL_MAX and err.mean().item() <= TOL_MEAN
+    again = net.decode_batch(mel.to(gpu_device))                          # halos are refilled on every call
+    assert torch.equal(again, wav)

@@ -65,6 +65,24 @@ def test_lmac_metrics_kernel(gpu_device):
     assert torch.allclose(pc[4], lmac_ref.compute_AG(t, p), rtol=1e-6, atol=1e-5)
 
 
+def test_lmac_metrics_kernel_golden(gpu_device, golden):
+    """advh_lmac_metrics_accumulate against the reference's own metric functions (tests/golden/lmac_metrics.npz, generated
+    from LMAC_metrics.py:31-73): per-clip faithfulness / fidelity / AI bit-exact, AD / AG to 1e-6 relative (one division),
+    the five dataset means to 1e-6."""
+    g = golden("lmac_metrics.npz")
+    d = gpu_device
+    p, t, o = (torch.from_numpy(g[k]).to(d) for k in ("predictions", "theta_out", "masked_predictions"))
+    got, pc = P.lmac_metrics(p, t, o, per_clip=True)
+    pc = pc.cpu()
+    assert torch.equal(pc[0], torch.from_numpy(g["faithfulness"]))
+    assert torch.equal(pc[1], torch.from_numpy(g["fidelity"]))
+    assert torch.allclose(pc[2], torch.from_numpy(g["AD"]), rtol=1e-6, atol=1e-6)
+    assert torch.equal(pc[3], torch.from_numpy(g["AI"]))
+    assert torch.allclose(pc[4], torch.from_numpy(g["AG"]), rtol=1e-6, atol=1e-5)
+    for k, v in zip(P.METRIC_NAMES, g["means"]):
+        assert abs(got[k] - float(v)) <= 1e-6 * max(1.0, abs(float(v))), (k, got[k], v)
+
+
 def test_full_batch_properties(gpu_device):
     """BASELINE batch (64 x 4 s): size-independent properties, no oracle needed."""
     cfg = syn.base_config()

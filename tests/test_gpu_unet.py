@@ -35,7 +35,7 @@ def check(mask, ref):
 @pytest.mark.parametrize("shape", [(2, 32, 8), (1, 64, 16), (3, 48, 20)])
 def test_unet_small(gpu_device, shape, golden):
     sd = syn.unet_weights()
-    net = HipUNet(sd, gpu_device)
+    net = HipUNet(sd, gpu_device, precision="f16")
     B, H, W = shape
     r = np.random.Generator(np.random.PCG64(41))
     if shape == (2, 32, 8):
@@ -61,9 +61,9 @@ def test_unet_fused_up_matches_unfused(gpu_device, shape):
     r = np.random.Generator(np.random.PCG64(7 + H))
     x = torch.from_numpy(r.uniform(0, 3, size=(B, 1, H, W)).astype(np.float32))
     ref = unet_ref.unet_forward(x, sd)[:, 0]
-    fused = HipUNet(sd, gpu_device, fuse_up=True).forward(x[:, 0].to(gpu_device), H=H, W=W)
-    plain = HipUNet(sd, gpu_device, fuse_up=False).forward(x[:, 0].to(gpu_device), H=H, W=W)
-    gemm_only = HipUNet(sd, gpu_device, fuse_up=True, line_tile=False).forward(x[:, 0].to(gpu_device), H=H, W=W)
+    fused = HipUNet(sd, gpu_device, fuse_up=True, precision="f16").forward(x[:, 0].to(gpu_device), H=H, W=W)
+    plain = HipUNet(sd, gpu_device, fuse_up=False, precision="f16").forward(x[:, 0].to(gpu_device), H=H, W=W)
+    gemm_only = HipUNet(sd, gpu_device, fuse_up=True, line_tile=False, precision="f16").forward(x[:, 0].to(gpu_device), H=H, W=W)
     check(fused, ref)
     check(plain, ref)
     check(gemm_only, ref)
@@ -75,7 +75,7 @@ def test_unet_fused_up_matches_unfused(gpu_device, shape):
 def test_unet_full_size(gpu_device, golden):
     """512 x 196 crop of a real 4 s STFT magnitude (the BASELINE shape), one clip + batch neighbours."""
     sd = syn.unet_weights()
-    net = HipUNet(sd, gpu_device)
+    net = HipUNet(sd, gpu_device, precision="f16")
     w = syn.make_clips(3, 64000)
     _, mag, _ = ops.stft_forward(w.to(gpu_device), 64000, want_complex=False, want_phase=False)
     mask = net.forward(mag)                                   # crops to 512 x 196 by indexing

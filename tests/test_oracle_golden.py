@@ -89,6 +89,23 @@ def test_embedder_base_full(golden):
     assert abs(f.abs().max().item() - float(g["absmax"])) < 1e-4
 
 
+def test_embedder_large_full(golden):
+    """wav2vec2-large (layer-norm feature extractor, pre-LN encoder: BASELINE config 5's embedder), one 4 s clip, against
+    the reference's own extract_features and the HF model's per-layer moments (tests/golden/make_golden.py large)."""
+    g = golden("embedder_large_4s.npz")
+    cfg = syn.large_config()
+    sd = syn.embedder_weights(cfg)
+    w = syn.make_clips(1, 64000)
+    hs = wav2vec2_ref.hidden_states(wav2vec2_ref.zero_mean_unit_var_norm(w), sd, cfg, upto=9)
+    f = hs[9][0]
+    assert tuple(f.shape) == tuple(g["shape"])
+    close(f[:8, :16], g["corner"], 1e-4)
+    close(f.mean(0), g["pooled"], 5e-5)
+    for i in range(10):
+        assert abs(hs[i].double().mean().item() - g["layer_mean"][i]) < 1e-5 + 1e-4 * abs(g["layer_mean"][i]), i
+        assert abs(hs[i].double().std().item() - g["layer_std"][i]) < 1e-4 * g["layer_std"][i], i
+
+
 def test_unet(golden):
     g = golden("unet.npz")
     sd = syn.unet_weights()
@@ -137,3 +154,20 @@ def test_lmac_metric_table():
     assert lmac_ref.compute_AI(th, p).tolist() == [0, 100, 100, 0, 0]
     ag = lmac_ref.compute_AG(th, p)
     np.testing.assert_allclose(ag.numpy(), [0, 100 * 0.1 / 0.2, 100 * 0.1 / 0.5, 0, 0], atol=1e-3)
+
+
+def test_lmac_metrics_golden(golden):
+    """The oracle's five metric functions against the REFERENCE's own (LMAC_metrics.py:31-73 compiled from its source by
+    tests/golden/make_golden.py): 64 (p, theta, p_out) triples incl. ties at exactly 0.5, saturation at 0 / 1 and label
+    flips.  Bit-exact: the restatement is the same fp32 expression tree."""
+    g = golden("lmac_metrics.npz")
+    p, th, po = T(g["predictions"]), T(g["theta_out"]), T(g["masked_predictions"])
+    assert torch.equal(lmac_ref.get_score_for_predicted_class(p.squeeze(1)), T(g["score"]))
+    assert torch.equal(lmac_ref.compute_faithfulness(p, po), T(g["faithfulness"]))
+    assert torch.equal(lmac_ref.compute_fidelity(th, p).view(-1), T(g["fidelity"]))
+    assert torch.equal(lmac_ref.compute_AD(th, p), T(g["AD"]))
+    assert torch.equal(lmac_ref.compute_AI(th, p), T(g["AI"]))
+    assert torch.equal(lmac_ref.compute_AG(th, p), T(g["AG"]))
+    m = lmac_ref.lmac_summary(p, th, po)
+    for k, v in zip(("faithfulness", "fidelity", "AD", "AI", "AG"), g["means"]):
+        assert abs(m[k] - float(v)) <= 1e-6 * max(1.0, abs(float(v))), (k, m[k], v)

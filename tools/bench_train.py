@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Training step of the mask decoder (train_addvisor.py:364-381) with the drop-in modules on one MI355X:
-U-Net forward/backward (HIP training kernels; ADDVISOR_UNET_TRAIN=torch for torch's GPU convolutions) + HIP LMAC loss forward/backward (ISTFT x2, wav2vec2-base x2 with saves, their
+U-Net forward/backward (HIP training kernels) + HIP LMAC loss forward/backward (ISTFT x2, wav2vec2-base x2 with saves, their
 input-gradient chain, ISTFT adjoint x2) + Adam.  usage: bench_train.py [B] [audio_length_s]"""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -54,7 +54,7 @@ tm, vals = [], []
 for _ in range(5):
     vals.append(step(tm))
 u, l, b = (1e3 * sum(t[i] for t in tm) / len(tm) for i in range(3))
-print(json.dumps({"workload": f"mask-decoder training step, batch {B} x {AL} s, wav2vec2-base (frozen), U-Net path " + os.environ.get("ADDVISOR_UNET_TRAIN", "hip") + ", HIP LMAC loss fwd/bwd",
+print(json.dumps({"workload": f"mask-decoder training step, batch {B} x {AL} s, wav2vec2-base (frozen), HIP U-Net training kernels, HIP LMAC loss fwd/bwd",
                   "ms_per_step": round(u + l + b, 2), "clips_per_s": round(B / (u + l + b) * 1e3, 1),
                   "unet_forward_ms": round(u, 2), "hip_loss_forward_and_grad_ms": round(l, 2),
                   "unet_backward_plus_adam_ms": round(b, 2), "loss_values": [round(v, 4) for v in vals]}))

@@ -27,7 +27,8 @@ class ConvBlock(nn.Module):
         )
 
     def forward(self, x):
-        """Only used by the training path of ``UNet.forward`` (autograd through torch's GPU convolutions)."""
+        """The reference's module forward (addvisor.py:24-25).  ``UNet.forward`` never calls it: the arithmetic of the
+        whole network runs on the HIP kernels; it exists so code that holds a bare ConvBlock keeps working."""
         return self.block(x)
 
 
@@ -75,18 +76,17 @@ class UNet(nn.Module):
             raise RuntimeError(f"U-Net skip connections need F % 16 == 0 and T % 4 == 0, got {Fq}x{Tq}")
         dev = torch.device("cuda")
         if self.training and torch.is_grad_enabled():
-            # Training step (train_addvisor.py:364-378): the mask carries an autograd graph back to the parameters.
-            # On a GPU that graph is ONE autograd.Function over the HIP training kernels (addvisor_hip/unet_train.py:
-            # batch-statistics BatchNorm, dgrad / wgrad as implicit GEMMs); parameters stay ordinary nn.Parameters, so
-            # torch optimisers and DistributedDataParallel (RCCL gradient all-reduce) work unchanged.  On the CPU
-            # (the gloo rehearsal of the data-parallel step) or with ADDVISOR_UNET_TRAIN=torch the registered torch
-            # modules run instead.
+            # Training step (train_addvisor.py:364-378): the mask carries an autograd graph back to the parameters:
+            # ONE autograd.Function over the HIP training kernels (addvisor_hip/unet_train.py: batch-statistics
+            # BatchNorm, dgrad / wgrad as implicit GEMMs).  Parameters stay ordinary nn.Parameters, so torch optimisers
+            # and DistributedDataParallel (RCCL gradient all-reduce) work unchanged.  There is no eager-torch path: the
+            # parameters must live on the GPU.
             self._hip = None                                   # weights change: repack before the next inference forward
             pdev = self.mask_head[0].weight.device
-            if pdev.type == "cuda" and os.environ.get("ADDVISOR_UNET_TRAIN", "hip") != "torch":
-                mask = self._forward_hip_train(x4.to(pdev, torch.float32))
-            else:
-                mask = self._forward_autograd(x4.to(pdev, torch.float32))
+            if pdev.type != "cuda":
+                raise RuntimeError("UNet training runs on the HIP kernels only: move the module to the GPU (.to('cuda')); "
+                                   "there is no CPU / eager-PyTorch path")
+            mask = self._forward_hip_train(x4.to(pdev, torch.float32))
             return mask[:, 0] if squeeze else mask
         if self.training and not self._warned:
             warnings.warn("UNet is in training mode but gradients are disabled; the HIP path uses eval-mode "
@@ -104,20 +104,6 @@ class UNet(nn.Module):
         self._train_engine.p = tensors
         return _UNetTrainFn.apply(self._train_engine, x, names, *[p for _, p in self.named_parameters()])
 
-    def _forward_autograd(self, x):
-        """addvisor.py:62-84 on the registered torch modules (encoder, dilated bottleneck, transposed-conv
-        upsampling with skip concatenation, 1x1 sigmoid head)."""
-        x1 = self.e1(x)
-        x2 = self.e2(x1)
-        x3 = self.e3(x2)
-        x4 = self.e4(x3)
-        b = self.bottleneck(x4)
-        y4 = self.d4(torch.cat([self.up4(b), x3], 1))
-        y3 = self.d3(torch.cat([self.up3(y4), x2], 1))
-        y2 = self.d2(torch.cat([self.up2(y3), x1], 1))
-        y1 = self.d1(torch.cat([self.up1(y2), x], 1))
-        return self.mask_head(y1)
-
 
 class _UNetTrainFn(torch.autograd.Function):
     """mask = UNet(x) in train() mode and its backward, both on the HIP kernels."""
@@ -126,10 +112,16 @@ class _UNetTrainFn(torch.autograd.Function):
     def forward(ctx, engine, x, names, *params):
         ctx.engine, ctx.names, ctx.shapes = engine, names, [p.shape for p in params]
         B, _, H, W = x.shape
-        return engine.forward(x[:, 0].contiguous(), H=H, W=W)[:, None]
+        mask = engine.forward(x[:, 0].contiguous(), H=H, W=W)[:, None]
+        ctx.generation = engine.generation               # the engine keeps ONE set of saved activations: stamp this forward
+        return mask
 
     @staticmethod
     def backward(ctx, gmask):
+        if ctx.generation != ctx.engine.generation:
+            raise RuntimeError("UNet: backward of a training forward whose saved activations were overwritten by a later "
+                               "training forward of the same module (the HIP engine keeps one set); call backward() "
+                               "before the next forward, or accumulate gradients step by step")
         grads = ctx.engine.backward(gmask[:, 0])
         return (None, None, None) + tuple(grads[k].reshape(s) for k, s in zip(ctx.names, ctx.shapes))
 

@@ -53,6 +53,8 @@ SIGNATURES = {
     "advh_unet_head": (_i, [_p, _i, _i, _i, _i, _i, _p, _f, _p, _p, _p]),
     "advh_lmac_metrics_accumulate": (_i, [_p, _p, _p, _i, _p, _p, _p]),
     "advh_hifigan_pack_mel": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "advh_hifigan_pack_mel_pad": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
+    "advh_halo_fill_f16": (_i, [_p, _i, _i, _i, _i, _i, _p]),
     "advh_hifigan_mrf_mix": (_i, [_p, _p, _p, _p, _f, _i64, _p]),
     "advh_hifigan_conv_post": (_i, [_p, _p, _f, _p, _i, _i, _i, _i, _i, _p]),
     "advh_mel_log": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),

@@ -113,6 +113,15 @@ class HipEmbedder:
         self._ws: Dict[Tuple[int, int, int], dict] = {}
         self._wcache: dict = {}                    # packed fp16 weights, shared by the plans of every batch shape
 
+    def f16_twin(self) -> "HipEmbedder":
+        """The fp16-operand instance of the same model: the input-gradient chain (``EmbedderGrad``: Saliency / IG / LMAC
+        loss backward) runs on the fp16 kernels and shares the forward plans of an fp16 embedder."""
+        if not self.split:
+            return self
+        if getattr(self, "_twin", None) is None:
+            self._twin = HipEmbedder(self.cfg, self.sd, self.coef.cpu().numpy(), self.intercept, self.dev, precision="f16")
+        return self._twin
+
     # ------------------------------------------------------------------ planning (once per batch shape)
     def _lengths(self, L: int) -> List[int]:
         out, n = [], L

@@ -49,6 +49,7 @@ def plan_conv1d_dgrad(B: int, P_out: int, weight: torch.Tensor, stride: int, dev
 
 class EmbedderGrad:
     def __init__(self, emb: HipEmbedder):
+        emb = emb.f16_twin()                                   # the backward chain is built on the fp16 kernels
         self.emb = emb
         self.cfg, self.dev, self.sd = emb.cfg, emb.dev, emb.sd
         self.layer_mode = emb.layer_mode                       # "layer" feature extractor (wav2vec2-large / xls-r)

@@ -5,6 +5,14 @@ implicit-GEMM launch on zero-haloed channels-last fp16 maps (``gemm.plan_conv1d_
 ``plan_convT1d``); LeakyReLU is applied by the producer (each GEMM writes the raw map for the residual
 path and, through ``out_h2``, the pre-activated copy the next conv reads), the MRF average and the
 1-channel conv_post + tanh are small direct kernels.  Weight-norm is assumed folded (inference form).
+
+Fidelity options.  The reference reaches the generator through SpeechBrain's wrapper, whose source is not available
+offline; two of its choices change the numbers and are therefore options here, mirrored by ``oracle/hifigan_ref.py``:
+``padding_mode`` of the "same" Conv1d layers ("zeros" = the published Kong et al. model, the default; "reflect" = the
+default of SpeechBrain's ``Conv1d``) and ``inference_padding`` (mel frames replicated on both sides before the
+generator, output length ``(T + 2 p) * 256``; 0 = off, the default; SpeechBrain / Coqui generators ship with 5).
+"reflect" fills the map halos with the mirrored interior after every producing launch (``advh_halo_fill_f16``); the
+fused line-tile kernels keep their intermediate in LDS with zero padding, so that mode runs the implicit GEMM only.
 """
 from __future__ import annotations
 
@@ -19,11 +27,20 @@ HALO = 32          # >= the largest "same" padding: (11 - 1) * 5 / 2 = 25
 
 
 class HipHifigan:
-    def __init__(self, cfg: HifiganConfig, sd: Dict[str, torch.Tensor], device, line_tile: bool = True, fuse: bool = True):
+    def __init__(self, cfg: HifiganConfig, sd: Dict[str, torch.Tensor], device, line_tile: bool = True, fuse: bool = True,
+                 padding_mode: str = "zeros", inference_padding: int = 0):
         """``line_tile``: run the 32- / 64-channel ResBlock convolutions on the weights-in-LDS kernel
         (``advh_conv_taps_f16``) instead of the implicit GEMM; ``fuse``: whole ResBlock steps in one kernel where both
-        weight tensors fit in LDS (``advh_resblock_pair_f16``)."""
+        weight tensors fit in LDS (``advh_resblock_pair_f16``).  ``padding_mode`` / ``inference_padding``: see the module
+        docstring."""
         _lib.init()
+        if padding_mode not in ("zeros", "reflect"):
+            raise ValueError("padding_mode must be 'zeros' or 'reflect'")
+        if inference_padding < 0:
+            raise ValueError("inference_padding must be >= 0")
+        self.padding_mode, self.inference_padding = padding_mode, int(inference_padding)
+        if padding_mode == "reflect":
+            line_tile = fuse = False                       # the fused kernels zero-pad their LDS intermediate
         self.cfg, self.dev, self.line_tile, self.fuse = cfg, device, line_tile, fuse
         self.sd = {k: v.detach().float() for k, v in sd.items()}
         ch = cfg.upsample_initial_channel
@@ -52,10 +69,14 @@ class HipHifigan:
             return G.plan_conv1d_same(src, dst, w, b, device=dev, **kw)
 
         ch = cfg.upsample_initial_channel
+        reflect = self.padding_mode == "reflect"
         mel = M(T, cfg.in_channels)
         cur = M(T, ch)                       # lrelu(conv_pre(mel))
-        steps = [("gemm", G.plan_conv1d_same(mel, cur, sd["conv_pre.weight"], sd["conv_pre.bias"], act="leaky",
-                                             slope=cfg.leaky_slope, device=dev), mel, None, cur, None)]
+        steps = []
+        if reflect:
+            steps.append(("halo", 1, mel, None, None, None))
+        steps.append(("gemm", G.plan_conv1d_same(mel, cur, sd["conv_pre.weight"], sd["conv_pre.bias"], act="leaky",
+                                                 slope=cfg.leaky_slope, device=dev), mel, None, cur, None))
         t = T
         nk, nd = len(cfg.resblock_kernel_sizes), len(cfg.resblock_dilations)
         nstage = len(cfg.upsample_rates)
@@ -69,6 +90,9 @@ class HipHifigan:
             lx = None if in_lds else M(t2, co)
             steps.append(("gemm", G.plan_convT1d(cur, x, sd[f"ups.{i}.weight"], sd[f"ups.{i}.bias"], stride=r,
                                                  slope2=cfg.leaky_slope, device=dev), cur, None, x, lx))
+            if reflect:                                    # the ResBlock convolutions read x / lrelu(x) reflect-padded
+                steps.append(("halo", 1, x, None, None, None))
+                steps.append(("halo", 1, lx, None, None, None))
             tmp, pa, pb = M(t2, co), M(t2, co), M(t2, co)
             la, lb = (None, None) if in_lds else (M(t2, co), M(t2, co))
             outs = [M(t2, co) for _ in range(nk)]
@@ -92,12 +116,20 @@ class HipHifigan:
                                                **(dict(pre_slope=cfg.leaky_slope) if in_lds else {})),
                                   c1_src, None, tmp, None))
                     ol = None if (last or in_lds) else (la if d % 2 == 0 else lb)
+                    if reflect:
+                        steps.append(("halo", 1, tmp, None, None, None))
                     steps.append(("gemm", conv(tmp, ox, sd[p + f"convs2.{d}.weight"], sd[p + f"convs2.{d}.bias"],
                                                slope2=cfg.leaky_slope), tmp, cx, ox, ol))
+                    if reflect and ol is not None:         # the next conv1 reads lrelu(x) reflect-padded (the raw ox only feeds residuals)
+                        steps.append(("halo", 1, ol, None, None, None))
                     cx, clx = ox, ol
             nxt = M(t2, co)
             slope = cfg.leaky_slope if i < nstage - 1 else 0.01            # F.leaky_relu default before conv_post
             steps.append(("mix", slope, outs, None, nxt, None))
+            if reflect:
+                # the mix runs over whole padded maps; the transposed convolution that follows needs a ZERO halo (it is not a
+                # "same" conv), conv_post a reflected one
+                steps.append(("halo", 1 if i == nstage - 1 else 0, nxt, None, None, None))
             cur, ch, t = nxt, co, t2
         ws = dict(mel=mel, steps=steps, last=cur, T_out=t, wav=torch.empty(B, 1, t, dtype=torch.float32, device=dev))
         ws["flops"] = sum(s[1].flops for s in steps if s[0] == "gemm") + 2.0 * B * t * ch * cfg.post_kernel
@@ -114,13 +146,20 @@ class HipHifigan:
         if mel.dim() != 3 or mel.shape[1] != self.cfg.in_channels:
             raise ValueError(f"mel must be [B, {self.cfg.in_channels}, T]")
         mel = mel.to(self.dev, torch.float32).contiguous()
-        B, C, T = mel.shape
+        B, C, T0 = mel.shape
+        pad = self.inference_padding
+        T = T0 + 2 * pad
         ws = self._workspace(B, T)
         lib, st = _lib.lib(), torch.cuda.current_stream().cuda_stream
-        _lib.check(lib.advh_hifigan_pack_mel(mel.data_ptr(), ws["mel"].t.data_ptr(), B, C, T, HALO, st), "advh_hifigan_pack_mel")
+        if pad:
+            _lib.check(lib.advh_hifigan_pack_mel_pad(mel.data_ptr(), ws["mel"].t.data_ptr(), B, C, T0, pad, HALO, st), "advh_hifigan_pack_mel_pad")
+        else:
+            _lib.check(lib.advh_hifigan_pack_mel(mel.data_ptr(), ws["mel"].t.data_ptr(), B, C, T, HALO, st), "advh_hifigan_pack_mel")
         for kind, plan, src, resid, dst, dst2 in ws["steps"]:
             if kind == "gemm":
                 plan.run(src.t, out_h=dst.t, resid=None if resid is None else resid.t, out_h2=None if dst2 is None else dst2.t)
+            elif kind == "halo":
+                _lib.check(lib.advh_halo_fill_f16(src.t.data_ptr(), src.B, src.T, src.C, src.halo, plan, st), "advh_halo_fill_f16")
             else:
                 a, b, c = src
                 _lib.check(lib.advh_hifigan_mrf_mix(a.t.data_ptr(), b.t.data_ptr(), c.t.data_ptr(), dst.t.data_ptr(), plan,

@@ -37,6 +37,16 @@ class _LMACTerms(torch.autograd.Function):
         if need:
             seed = torch.cat([torch.sigmoid(l_rel) - cp, torch.sigmoid(l_irr) - (1 - cp)]) / B
             g = eg.backward(loss_scale, seed=seed)                          # dL/d wave, [2B, length]
+            # fp16 gradients between the dgrad GEMMs: an overflow shows up as inf / NaN here.  Back the power-of-two scale
+            # off (exact) and redo the backward rather than hand a poisoned gradient to the optimiser (GradScaler's rule).
+            tries = 0
+            while not bool(torch.isfinite(g).all()) and tries < 6:
+                loss_scale *= 1.0 / 16.0
+                tries += 1
+                g = eg.backward(loss_scale, seed=seed)
+            if tries and not bool(torch.isfinite(g).all()):
+                raise FloatingPointError("LMAC loss backward: non-finite input gradient at every loss scale down to "
+                                         f"{loss_scale:g}")
             g_in = ops.istft_masked_bwd(g[:B], mag, phase, m, 0, domain="linear", hop=hop, win=win)
             g_out = ops.istft_masked_bwd(g[B:], mag, phase, m, 1, domain="linear", hop=hop, win=win)
             ctx.save_for_backward(g_in, g_out, m)

@@ -11,12 +11,12 @@ obtains bit-identical metrics for any world size.
 """
 from __future__ import annotations
 
-from typing import Dict
+from typing import Dict, Optional
 
 import torch
 
 from . import _lib, ops
-from .embedder import HipEmbedder
+from .embedder import HipEmbedder, default_precision
 from .synthetic import EmbedderConfig
 from .unet import HipUNet
 
@@ -26,16 +26,18 @@ METRIC_NAMES = ("faithfulness", "fidelity", "AD", "AI", "AG")
 class ExplainPipeline:
     def __init__(self, emb_cfg: EmbedderConfig, emb_sd, coef, intercept, unet_sd, device,
                  audio_length: float = 4, sampling_rate: int = 16000, domain: str = "log1p",
-                 hop: int = 322, win: int = 644, streams: int = 1, vocoder=None):
-        """``vocoder``: an ``addvisor_hip.hifigan.HipHifigan``; when given, the mask-in / mask-out resyntheses are
+                 hop: int = 322, win: int = 644, streams: int = 1, vocoder=None, precision: Optional[str] = None):
+        """``precision``: "f32" (fp32-class split-format kernels: the reference's arithmetic class, the default) or "f16"
+        (fp16 operands; 2-3x faster); ``None`` = ``ADDVISOR_PRECISION``.  ``vocoder``: an ``addvisor_hip.hifigan.HipHifigan``; when given, the mask-in / mask-out resyntheses are
         re-rendered by the vocoder (mel front end of hifigan.py:163-178 -> HiFi-GAN V1 -> crop to the clip length)
         before the classifier re-forward -- the "masked spectrogram -> vocoder -> classifier" variant of the path."""
         self.dev = device
         self.vocoder = vocoder
         self.L = int(audio_length * sampling_rate)
         self.hop, self.win, self.domain = hop, win, domain
-        self.embedder = HipEmbedder(emb_cfg, emb_sd, coef, intercept, device)
-        self.unet = HipUNet(unet_sd, device)
+        self.precision = precision or default_precision()
+        self.embedder = HipEmbedder(emb_cfg, emb_sd, coef, intercept, device, precision=self.precision)
+        self.unet = HipUNet(unet_sd, device, precision=self.precision)
         # the 3B embedder batch can be split over several HIP streams: kernels of independent sub-batches then
         # fill each other's tail waves and launch gaps (utterances are independent)
         self.nstreams = max(1, streams)

@@ -9,6 +9,7 @@ default, since none of those artefacts exist offline -- from the seeded syntheti
                           (config.json + model.safetensors / pytorch_model.bin of a Wav2Vec2Model)
     ADDVISOR_LOGREG       .npz with coef_ / intercept_, or a sklearn .joblib       (default: synthetic)
     ADDVISOR_LAYER_INDEX  hidden-state index returned by extract_features            (default 9)
+    ADDVISOR_PRECISION    f32 (default: fp32-class split-format kernels, the reference's arithmetic class) | f16
 """
 from __future__ import annotations
 

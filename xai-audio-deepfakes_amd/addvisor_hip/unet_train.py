@@ -155,6 +155,7 @@ class HipUNetTrain:
         self.nparts = _lib.lib().advh_bn_partial_count()
         self._ws: Dict[Tuple[int, int, int], dict] = {}
         self._last = None
+        self.generation = 0                                    # bumped by every forward: backward() belongs to the latest one
 
     # ------------------------------------------------------------------------------------------ workspace
     def _workspace(self, B: int, H: int, W: int) -> dict:
@@ -349,6 +350,7 @@ class HipUNetTrain:
         _lib.check(lib.advh_unet_head(y1.t.data_ptr(), B, H, W, y1.PH, y1.PW, hw.data_ptr(), hb, ws["mask"].data_ptr(),
                                       ws["logits"].data_ptr(), st), "advh_unet_head")
         self._last = (mag, B, Fq, Tq, H, W, hw)
+        self.generation += 1
         return ws["mask"].clone()
 
     # ------------------------------------------------------------------------------------------ backward

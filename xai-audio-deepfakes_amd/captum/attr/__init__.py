@@ -47,7 +47,11 @@ class IntegratedGradients(_Method):
     def attribute(self, inputs, baselines=None, target=None, additional_forward_args=None, n_steps=50,
                   method="gausslegendre", internal_batch_size=None, return_convergence_delta=False):
         self._check(inputs, target)
-        if baselines is not None and not (torch.is_tensor(baselines) and not baselines.any()) and baselines != 0:
+        if torch.is_tensor(baselines):
+            zero = not bool(baselines.any())
+        else:
+            zero = baselines is None or (isinstance(baselines, (int, float)) and baselines == 0)
+        if not zero:
             raise NotImplementedError("only the zero baseline (Captum's default) is built")
         if method != "gausslegendre":
             raise NotImplementedError("only Captum's default 'gausslegendre' rule is built")

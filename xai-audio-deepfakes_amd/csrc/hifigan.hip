@@ -21,6 +21,40 @@ __global__ __launch_bounds__(256) void pack_mel_kernel(const float* __restrict__
     out[((long)b * (T + 2 * halo) + t + halo) * C + c] = (_Float16)mel[((long)b * C + c) * T + t];
 }
 
+// Same with `pad` replicated frames in front and behind (SpeechBrain / Coqui `inference_padding`: F.pad(mel, (p, p),
+// "replicate") before the generator); the map holds T + 2 pad interior rows.
+__global__ __launch_bounds__(256) void pack_mel_pad_kernel(const float* __restrict__ mel, _Float16* __restrict__ out,
+                                                           int C, int T, int pad, int halo, long total) {
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int Tp = T + 2 * pad;
+    int c = (int)(i % C);
+    long r = i / C;
+    int t = (int)(r % Tp), b = (int)(r / Tp);
+    int ts = min(max(t - pad, 0), T - 1);
+    out[((long)b * (Tp + 2 * halo) + t + halo) * C + c] = (_Float16)mel[((long)b * C + c) * T + ts];
+}
+
+// Halo fill of a channels-last map [B][T + 2 halo][C]: mode 0 = zeros, mode 1 = reflection about the first / last
+// sample (x[-j] = x[j], x[T-1+j] = x[T-1-j]; torch "reflect" padding), for j = 1 .. min(halo, T - 1); rows beyond stay zero.
+// Lets the "same" Conv1d layers read a reflect-padded input (SpeechBrain's Conv1d default padding_mode) from the map itself.
+__global__ __launch_bounds__(256) void halo_fill_kernel(_Float16* __restrict__ x, int T, int C, int halo, int mode, long total) {
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c8 = C / 8;
+    int c = (int)(i % c8);
+    long r = i / c8;
+    int j = (int)(r % (2 * halo)), b = (int)(r / (2 * halo));
+    const long base = (long)b * (T + 2 * halo);
+    int dst, src;
+    if (j < halo) { dst = halo - 1 - j; src = halo + 1 + j; }               // x[-(j+1)] <- x[j+1]
+    else { const int jj = j - halo; dst = halo + T + jj; src = halo + T - 2 - jj; }
+    f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int dist = j < halo ? j + 1 : j - halo + 1;
+    if (mode == 1 && dist <= T - 1) v = *(const f16x8*)(x + (base + src) * C + c * 8);
+    *(f16x8*)(x + (base + dst) * C + c * 8) = v;
+}
+
 // MRF mix: y = LeakyReLU_slope((a + b + c) / 3), whole padded maps (zero halo stays zero)
 __global__ __launch_bounds__(256) void mrf_mix_kernel(const f16x8* __restrict__ a, const f16x8* __restrict__ b,
                                                       const f16x8* __restrict__ c, f16x8* __restrict__ y, float slope, long n8) {
@@ -73,6 +107,21 @@ extern "C" int advh_hifigan_pack_mel(const float* mel, void* out, int B, int C, 
     if (!mel || !out || B <= 0 || C <= 0 || T <= 0 || halo < 0) return ADVH_EINVAL;
     long total = (long)B * C * T;
     hipLaunchKernelGGL(pack_mel_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, mel, (_Float16*)out, C, T, halo, total);
+    return ADVH_LAUNCH_CHECK();
+}
+
+extern "C" int advh_hifigan_pack_mel_pad(const float* mel, void* out, int B, int C, int T, int pad, int halo, advh_stream_t stream) {
+    if (!mel || !out || B <= 0 || C <= 0 || T <= 0 || halo < 0 || pad < 0) return ADVH_EINVAL;
+    long total = (long)B * C * (T + 2 * pad);
+    hipLaunchKernelGGL(pack_mel_pad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, mel, (_Float16*)out, C, T, pad, halo, total);
+    return ADVH_LAUNCH_CHECK();
+}
+
+extern "C" int advh_halo_fill_f16(void* x, int B, int T, int C, int halo, int mode, advh_stream_t stream) {
+    if (!x || B <= 0 || T <= 0 || C <= 0 || C % 8 || halo < 0 || (mode != 0 && mode != 1)) return ADVH_EINVAL;
+    if (halo == 0) return ADVH_OK;
+    long total = (long)B * 2 * halo * (C / 8);
+    hipLaunchKernelGGL(halo_fill_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (_Float16*)x, T, C, halo, mode, total);
     return ADVH_LAUNCH_CHECK();
 }
 

@@ -2,7 +2,10 @@
 ``mel_spectogram``, ``align_waveforms`` and the band-swap data generator (hifigan.py:139-230, SURVEY.md §8(f)
 rank 2) as functions.  Importing it runs nothing (the reference runs its dataset loop at import) and fetches nothing: the generator weights
 come from ``ADDVISOR_HIFIGAN`` (a ``.pth`` state dict named like ``addvisor_hip.synthetic.hifigan_weights``,
-weight-norm folded) or the seeded synthetic generator."""
+weight-norm folded) or the seeded synthetic generator.  ``ADDVISOR_HIFIGAN_PADDING`` = zeros (default) | reflect and
+``ADDVISOR_HIFIGAN_INFERENCE_PADDING`` = 0 (default) | n select the SpeechBrain wrapper's conv padding mode and mel edge
+padding (addvisor_hip/hifigan.py: unverifiable offline, so they are options; a real SpeechBrain checkpoint most likely
+wants reflect / 5)."""
 import os
 
 import torch
@@ -25,7 +28,8 @@ class _HifiGan:
             cfg = _syn.HifiganConfig()
             path = os.environ.get("ADDVISOR_HIFIGAN")
             sd = torch.load(path, map_location="cpu") if path else _syn.hifigan_weights(cfg)
-            self._net = HipHifigan(cfg, sd, _rt.device())
+            self._net = HipHifigan(cfg, sd, _rt.device(), padding_mode=os.environ.get("ADDVISOR_HIFIGAN_PADDING", "zeros"),
+                                   inference_padding=int(os.environ.get("ADDVISOR_HIFIGAN_INFERENCE_PADDING", "0")))
         return self._net
 
     @torch.no_grad()

@@ -15,9 +15,12 @@ audio_processor = AudioProcessor()
 
 
 class LMACLoss(nn.Module):
-    def __init__(self, reg_w_tv=0.00):
+    def __init__(self, reg_w_tv=0.00, loss_scale=4096.0):
+        """``loss_scale``: power-of-two scale of the fp16 gradients inside the frozen embedder's backward (backed off
+        automatically on overflow, addvisor_hip/lmac_loss.py); the reference's signature is ``LMACLoss(reg_w_tv=0.0)``."""
         super().__init__()
         self.reg_w_tv = reg_w_tv
+        self.loss_scale = float(loss_scale)
         self.w_raw = nn.Parameter(torch.tensor([3.0, 0.5, 3.0], requires_grad=True))     # loss_function.py:24
 
     @property
@@ -35,7 +38,8 @@ class LMACLoss(nn.Module):
         cp = class_pred.to(device, torch.float32)
         if torch.is_grad_enabled() and m.requires_grad:
             from addvisor_hip.lmac_loss import lmac_terms
-            losses = lmac_terms(m, mag, ph, cp, _rt.hip_embedder_grad(), L, hop=ap.hop_length, win=ap.win_length)
+            losses = lmac_terms(m, mag, ph, cp, _rt.hip_embedder_grad(), L, hop=ap.hop_length, win=ap.win_length,
+                                loss_scale=self.loss_scale)
         else:
             w_in, w_out = _ops.istft_masked(mag, ph, m.detach(), L, domain="linear", hop=ap.hop_length, win=ap.win_length)
             emb = _rt.hip_embedder()
