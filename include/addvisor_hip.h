@@ -71,6 +71,13 @@ int advh_istft_masked(const float* mag, const float* phase, const float* mask, i
                       float* wave_in, float* wave_out, int64_t wave_stride, int B, int T, int L, int hop,
                       int win, const float* window, advh_stream_t stream);
 
+/* Same resynthesis from the COMPLEX spectrogram X [B][513][T][2] (advh_stft_forward's X) instead of (|X|, angle X):
+ * X' = X * g(mask, |X|) / |X|, which equals g e^{j angle X} of loss_function.py:36-45 / LMAC_metrics.py:136-153 without the
+ * atan2 / sincos round trip (more accurate, and no transcendental per bin in the linear domain).  mode: LINEAR or LOG1P. */
+int advh_istft_masked_c64(const float* spec, const float* mask, int Fm, int Tm, int mode, float* wave_in, float* wave_out,
+                          int64_t wave_stride, int B, int T, int L, int hop, int win, const float* window,
+                          advh_stream_t stream);
+
 /* Plain ISTFT of a complex64 spectrogram [B][513][T][2] (audioprocessor.py:117-131). */
 int advh_istft_c64(const float* spec, float* wave, int64_t wave_stride, int B, int T, int L, int hop, int win,
                    const float* window, advh_stream_t stream);

@@ -97,6 +97,34 @@ def test_istft_masked_vs_oracle(gpu_device, domain):
         assert ((w_in + w_out).cpu() - w).abs().max().item() < 2 * TOL_WAVE
 
 
+@pytest.mark.parametrize("domain", ["linear", "log1p"])
+def test_istft_masked_complex_vs_oracle(gpu_device, domain):
+    """advh_istft_masked_c64 -- what the explanation pipeline runs: X' = X * g(mask, |X|) / |X| from the HIP forward's own
+    complex spectrogram, against the reference formulation g e^{j angle X} (loss_function.py:36-45, LMAC_metrics.py:136-153)
+    evaluated by the oracle; also against the (|X|, angle X) entry point, and the one-output calls against the two-output one."""
+    L = 64000
+    w = syn.make_clips(3, L, seed=9)
+    _, mag, ph = signal_ref.compute_stft(w, audio_length=4)
+    mask = torch.from_numpy(np.random.Generator(np.random.PCG64(5)).uniform(0, 1, size=(3, 512, 196)).astype(np.float32))
+    mask[0, :40, :30] = 0.0                                              # exact zeros and ones included
+    mask[1, 100:140] = 1.0
+    rel, irr = signal_ref.apply_mask(signal_ref.embed_mask(mask, 513, 199), mag, ph, domain)
+    ref_in = signal_ref.compute_invert_stft(rel, audio_length=4)
+    ref_out = signal_ref.compute_invert_stft(irr, audio_length=4)
+    d = gpu_device
+    X, gmag, gph = ops.stft_forward(w.to(d), L)
+    w_in, w_out = ops.istft_masked_c64(X, mask.to(d), L, domain=domain)
+    e_in, e_out = (w_in.cpu() - ref_in).abs().max().item(), (w_out.cpu() - ref_out).abs().max().item()
+    p_in, p_out = ops.istft_masked(gmag, gph, mask.to(d), L, domain=domain)
+    print(f"complex masked ISTFT ({domain}): err vs oracle {e_in:.2e} / {e_out:.2e}; vs polar entry point {(w_in - p_in).abs().max().item():.2e}")
+    assert e_in < TOL_WAVE and e_out < TOL_WAVE
+    assert (w_in - p_in).abs().max().item() < TOL_WAVE and (w_out - p_out).abs().max().item() < TOL_WAVE
+    assert torch.equal(ops.istft_masked_c64(X, mask.to(d), L, domain=domain, want_in=False)[1], w_out)
+    assert torch.equal(ops.istft_masked_c64(X, mask.to(d), L, domain=domain, want_out=False)[0], w_in)
+    if domain == "linear":
+        assert ((w_in + w_out).cpu() - w).abs().max().item() < 2 * TOL_WAVE
+
+
 def test_istft_errors(gpu_device):
     with pytest.raises(ValueError, match="ISTFT expects complex input!"):
         ops.istft_complex(torch.zeros(1, 513, 199, device=gpu_device), 64000)

@@ -40,6 +40,7 @@ SIGNATURES = {
     "advh_set_option": (_i, [C.c_char_p, _i]),
     "advh_stft_forward": (_i, [_p, _i64, _i, _i, _i, _i, _i, _p, _p, _p, _p, _i, _p]),
     "advh_istft_masked": (_i, [_p, _p, _p, _i, _i, _i, _p, _p, _i64, _i, _i, _i, _i, _i, _p, _p]),
+    "advh_istft_masked_c64": (_i, [_p, _p, _i, _i, _i, _p, _p, _i64, _i, _i, _i, _i, _i, _p, _p]),
     "advh_istft_c64": (_i, [_p, _p, _i64, _i, _i, _i, _i, _i, _p, _p]),
     "advh_gemm_f16": (_i, [_p, _i, _p]),
     "advh_w2v2_frontend": (_i, [_p, _i64, _i, _i, _i, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _i, _i, _i, _p]),

@@ -92,6 +92,31 @@ def istft_masked(mag: torch.Tensor, phase: torch.Tensor, mask: Optional[torch.Te
     return w_in, w_out
 
 
+def istft_masked_c64(spec: torch.Tensor, mask: torch.Tensor, length: int, domain: str = "log1p", want_in: bool = True,
+                     want_out: bool = True, hop: int = 322, win: int = 644, window: Optional[torch.Tensor] = None
+                     ) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]:
+    """:func:`istft_masked` from the complex spectrogram ``spec [B, 513, T]`` complex64 instead of ``(|X|, angle X)``:
+    ``X' = X * g(mask, |X|) / |X|`` -- the same masked signal (loss_function.py:36-45, LMAC_metrics.py:136-153) without the
+    atan2 / sincos round trip; both resyntheses come out of one launch that reads the spectrogram from HBM once."""
+    _lib.init()
+    if not torch.is_complex(spec) or spec.dtype != torch.complex64 or spec.dim() != 3 or spec.shape[1] != NBIN:
+        raise ValueError("spec must be complex64 [B, 513, T]")
+    sr = torch.view_as_real(spec.contiguous())
+    B, _, T = spec.shape
+    mode = {"linear": 1, "log1p": 2}[domain]
+    mask = _req(mask, torch.float32, "mask")
+    if mask.dim() != 3 or mask.shape[0] != B or mask.shape[1] > NBIN or mask.shape[2] > T:
+        raise ValueError("mask must be [B, Fm<=513, Tm<=T]")
+    if T != 1 + length // hop:
+        raise ValueError("T does not match length // hop + 1")
+    w_in = torch.empty((B, length), dtype=torch.float32, device=spec.device) if want_in else None
+    w_out = torch.empty((B, length), dtype=torch.float32, device=spec.device) if want_out else None
+    rc = _lib.lib().advh_istft_masked_c64(sr.data_ptr(), mask.data_ptr(), mask.shape[1], mask.shape[2], mode, _ptr(w_in), _ptr(w_out),
+                                          length, B, T, length, hop, win, _ptr(window), _stream())
+    _lib.check(rc, "advh_istft_masked_c64")
+    return w_in, w_out
+
+
 def istft_masked_bwd(g_wave: torch.Tensor, mag: torch.Tensor, phase: torch.Tensor, mask: torch.Tensor, which: int,
                      domain: str = "linear", hop: int = 322, win: int = 644,
                      window: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -47,7 +47,8 @@ class ExplainPipeline:
         """``waves [B, n]`` fp32 on the GPU -> clean / mask-in / mask-out probabilities ``[B,1]`` and the mask."""
         L = self.L
         B, n = waves.shape
-        _, mag, phase = ops.stft_forward(waves, L, self.hop, self.win, want_complex=False)
+        # X and |X| only: the masked resynthesis scales X itself (advh_istft_masked_c64), so no phase is computed or read
+        spec, mag, _ = ops.stft_forward(waves, L, self.hop, self.win, want_complex=True, want_phase=False)
         mask = self.unet.forward(mag)
         # clean clip, mask-in and mask-out resyntheses go through the embedder as ONE 3B batch
         allw = torch.empty((3 * B, L), dtype=torch.float32, device=waves.device)
@@ -56,11 +57,11 @@ class ExplainPipeline:
         else:
             allw[:B, :n].copy_(waves)
             allw[:B, n:].zero_()
-        rc = _lib.lib().advh_istft_masked(
-            mag.data_ptr(), phase.data_ptr(), mask.data_ptr(), mask.shape[1], mask.shape[2],
+        rc = _lib.lib().advh_istft_masked_c64(
+            torch.view_as_real(spec).data_ptr(), mask.data_ptr(), mask.shape[1], mask.shape[2],
             {"linear": 1, "log1p": 2}[self.domain], allw[B:].data_ptr(), allw[2 * B:].data_ptr(), L, B, mag.shape[2], L,
             self.hop, self.win, None, torch.cuda.current_stream().cuda_stream)
-        _lib.check(rc, "advh_istft_masked")
+        _lib.check(rc, "advh_istft_masked_c64")
         if self.vocoder is not None:
             voc = self.vocoder.decode_batch(ops.mel_spectrogram(allw[B:]))[:, 0]        # [2B, 256 * (1 + L // 256)]
             k = min(L, voc.shape[1])
@@ -82,7 +83,7 @@ class ExplainPipeline:
         p_clean, p2, both = p3[:B], p3[B:], allw[B:]
         out = dict(predictions=p_clean, theta_out=p2[:B], masked_predictions=p2[B:], mask=mask)
         if keep:
-            out.update(mag=mag, phase=phase, wave_in=both[:B], wave_out=both[B:])
+            out.update(mag=mag, spec=spec, wave_in=both[:B], wave_out=both[B:])
         return out
 
     # ------------------------------------------------------------------ HIP graph replay (launch-bound small batches)

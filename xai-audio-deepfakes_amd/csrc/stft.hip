@@ -49,12 +49,39 @@ __device__ __forceinline__ void fft512_wave(float* re, float* im, int lane) {
     wave_fence();
 }
 
+// Row pitch of the LDS tile (words).  The spectrogram side of both kernels walks the tile TRANSPOSED -- lane -> (frame
+// tl = idx % FB, bin k = idx / FB) -- so 32 consecutive lanes touch FB rows x 32/FB neighbouring bins: conflict-free iff
+// pitch % 32 == 32 / FB (rows land 32/FB banks apart, the bins fill the gaps).  The plain FFT_ROW (530, % 32 = 18) gave
+// 2-way conflicts on a third of those accesses (round-1 PMC: 32.7 % of the forward kernel's LDS cycles).
+template <int FB> struct RowPitch { static constexpr int value = FFT_ROW + ((32 / FB - FFT_ROW % 32) + 32) % 32; };
+static_assert(RowPitch<8>::value % 32 == 4 && RowPitch<16>::value % 32 == 2, "row pitch");
+
 // LDS carve: re rows | im rows | scratch (samples for the forward, overlap-add accumulator for the inverse)
 template <int FB>
 __device__ __forceinline__ void carve(float* smem, float*& re, float*& im, float*& scratch) {
     re = smem;
-    im = smem + FB * FFT_ROW;
-    scratch = smem + 2 * FB * FFT_ROW;
+    im = smem + FB * RowPitch<FB>::value;
+    scratch = smem + 2 * FB * RowPitch<FB>::value;
+}
+
+// log1p / expm1 on the hardware log2 / exp2 units with Kahan's correction (log1p(x) = log(u) x / (u - 1), u = fl(1 + x);
+// expm1(y) = (u - 1) y / log(u), u = fl(e^y)): relative error <= ~4 ulp (5e-7) on the range the mask application uses
+// (x = |X| >= 0, y = m log1p|X| in [0, ~8]), against ~1 ulp at 3-4x the instructions for libm's log1pf / expm1f.
+__device__ __forceinline__ float fast_log1p(float x) {
+    const float u = 1.f + x, d = u - 1.f;
+    return d == 0.f ? x : __logf(u) * (x * __builtin_amdgcn_rcpf(d));
+}
+__device__ __forceinline__ float fast_expm1(float y) {
+    const float u = __expf(y), d = u - 1.f;
+    if (d == 0.f) return y;
+    return d * (y * __builtin_amdgcn_rcpf(__logf(u)));
+}
+// |X| of the mask application a' = g(m, |X|) as a FACTOR on X itself: X' = X * g / |X|  (= g e^{i angle X} without the
+// atan2 / sincos round trip).  linear: g / |X| = m;  log1p: expm1(m log1p M) / M -> m as M -> 0.
+__device__ __forceinline__ float mask_factor(float m, float M, int mode) {
+    if (mode == ADVH_MASK_LINEAR) return m;
+    if (M < 1e-12f) return m;
+    return fast_expm1(m * fast_log1p(M)) * __builtin_amdgcn_rcpf(M);
 }
 
 // ------------------------------------------------------------------------------------------ forward
@@ -73,6 +100,7 @@ __global__ __launch_bounds__(THREADS) void stft_fwd_kernel(
     const float* __restrict__ window, float* __restrict__ X, float* __restrict__ mag,
     float* __restrict__ phase, int T, AdjArgs adj) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int ROWP = RowPitch<FB>::value;
     float *re, *im, *smp;
     carve<FB>(smem, re, im, smp);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -108,8 +136,8 @@ __global__ __launch_bounds__(THREADS) void stft_fwd_kernel(
     // 2. one wavefront per frame: build z[n] = x[2n] + i x[2n+1], FFT512, real-transform glue
     for (int f = wv; f < FB; f += THREADS / 64) {
         if (tA + f >= T) break;                       // wave-uniform
-        float* rr = re + f * FFT_ROW;
-        float* ii = im + f * FFT_ROW;
+        float* rr = re + f * ROWP;
+        float* ii = im + f * ROWP;
         const float* fs = smp + f * hop;
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
@@ -152,7 +180,7 @@ __global__ __launch_bounds__(THREADS) void stft_fwd_kernel(
     for (int idx = tid; idx < NBIN * FB; idx += THREADS) {
         int tl = idx & (FB - 1), k = idx / FB;
         if (tl >= nvalid) continue;
-        float xr = re[tl * FFT_ROW + fidx(k)], xi = im[tl * FFT_ROW + fidx(k)];
+        float xr = re[tl * ROWP + fidx(k)], xi = im[tl * ROWP + fidx(k)];
         long o = ((long)b * NBIN + k) * T + tA + tl;
         if (ADJ) {
             const int t = tA + tl;
@@ -178,12 +206,16 @@ __global__ __launch_bounds__(THREADS) void stft_fwd_kernel(
             continue;
         }
         if (X) reinterpret_cast<float2*>(X)[o] = make_float2(xr, xi);
-        if (mag) mag[o] = hypotf(xr, xi);
+        if (mag) mag[o] = __builtin_sqrtf(fmaf(xr, xr, xi * xi));      // |X| <= 1024 max|x|: no overflow to guard against (hypotf's job)
         if (phase) phase[o] = atan2f(xi, xr);
     }
 }
 
 // ------------------------------------------------------------------------------------------ inverse
+// SRC 3: complex64 spectrogram X (in `mag`) + mask: X' = X * g(m, |X|) / |X| -- the mask application of SRC 0 without the
+// polar round trip (no atan2 in the forward, no sincos here); what the explanation pipeline runs.
+// SRC 0 / 3 with both outputs requested: ONE workgroup produces mask-in and mask-out in two passes over the same tile
+// (the second pass re-reads it from L2), so the spectrogram leaves HBM once per explanation, not once per resynthesis.
 // SRC 0: mag/phase (+ optional mask, mode), SRC 1: complex64 spectrogram, SRC 2: band swap of two complex64
 // spectrograms (hifigan.py:208-222, train_logReg_swapping.py:70-81): grid z = band, bins [Fm + z*Tm, Fm + (z+1)*Tm)
 // come from `phase` (the vocoded signal), all others from `mag` (the original); output z at out0 + z * out1_stride.
@@ -193,16 +225,20 @@ __global__ __launch_bounds__(THREADS) void istft_kernel(
     int Fm, int Tm, int mode, int which0, float* __restrict__ out0, float* __restrict__ out1,
     long wave_stride, int T, int L, int hop, int win, int R, const float* __restrict__ window, long zstride) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int ROWP = RowPitch<FB>::value;
     float *re, *im, *acc;
     carve<FB>(smem, re, im, acc);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int b = blockIdx.y, g = blockIdx.x;
-    const int which = which0 + blockIdx.z;            // 0: mask-in, 1: mask-out
-    float* out = (SRC == 2 ? out0 + (long)blockIdx.z * zstride : (blockIdx.z == 0 ? out0 : out1)) + (long)b * wave_stride;
     const int left = (NFFT - win) / 2;
     const int S = FB - R + 1;                         // complete hop-segments this workgroup emits
     const int tA = g * S - (R - 1);                   // first frame it transforms (may be < 0)
     const int nacc = (FB - 1) * hop + win;
+    const int npass = (SRC == 0 || SRC == 3) ? (out1 ? 2 : 1) : 1;
+    for (int pass = 0; pass < npass; ++pass) {
+    const int which = which0 + pass;                  // 0: mask-in, 1: mask-out
+    float* out = (SRC == 2 ? out0 + (long)blockIdx.z * zstride : (pass == 0 ? out0 : out1)) + (long)b * wave_stride;
+    if (pass) __syncthreads();                        // the accumulator of the previous pass has been emitted
 
     // 1. load the 513 x 16 tile, apply the mask and go polar -> cartesian
     for (int idx = tid; idx < NBIN * FB; idx += THREADS) {
@@ -217,21 +253,28 @@ __global__ __launch_bounds__(THREADS) void istft_kernel(
                 const int lo = Fm + (int)blockIdx.z * Tm;
                 float2 v = reinterpret_cast<const float2*>((k >= lo && k < lo + Tm) ? phase : mag)[o];
                 xr = v.x; xi = v.y;
+            } else if (SRC == 3) {
+                float2 v = reinterpret_cast<const float2*>(mag)[o];
+                float m = 0.f;
+                if (k < Fm && t < Tm) m = mask[((long)b * Fm + k) * Tm + t];
+                if (which == 1) m = 1.f - m;
+                const float f = mask_factor(m, __builtin_sqrtf(fmaf(v.x, v.x, v.y * v.y)), mode);
+                xr = v.x * f; xi = v.y * f;
             } else {
                 float a = mag[o], ph = phase[o];
                 if (mode != ADVH_MASK_NONE) {
                     float m = 0.f;
                     if (k < Fm && t < Tm) m = mask[((long)b * Fm + k) * Tm + t];
                     if (which == 1) m = 1.f - m;
-                    a = (mode == ADVH_MASK_LINEAR) ? m * a : expm1f(m * log1pf(a));
+                    a = (mode == ADVH_MASK_LINEAR) ? m * a : fast_expm1(m * fast_log1p(a));
                 }
                 float s, c;
                 sincosf(ph, &s, &c);
                 xr = a * c; xi = a * s;
             }
         }
-        re[tl * FFT_ROW + fidx(k)] = xr;
-        im[tl * FFT_ROW + fidx(k)] = xi;
+        re[tl * ROWP + fidx(k)] = xr;
+        im[tl * ROWP + fidx(k)] = xi;
     }
     for (int i = tid; i < nacc; i += THREADS) acc[i] = 0.f;
     __syncthreads();
@@ -240,8 +283,8 @@ __global__ __launch_bounds__(THREADS) void istft_kernel(
     for (int f = wv; f < FB; f += THREADS / 64) {
         int t = tA + f;
         if (t < 0 || t >= T) continue;                // wave-uniform
-        float* rr = re + f * FFT_ROW;
-        float* ii = im + f * FFT_ROW;
+        float* rr = re + f * ROWP;
+        float* ii = im + f * ROWP;
         cf A[4], Bv[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -291,9 +334,13 @@ __global__ __launch_bounds__(THREADS) void istft_kernel(
         }
         out[n] = env > 1e-11f ? acc[a] / env : 0.f;
     }
+    }   // pass
 }
 
-static size_t lds_bytes(int FB, int hop, int win) { return sizeof(float) * (2 * FB * FFT_ROW + (FB - 1) * hop + win); }
+static size_t lds_bytes(int FB, int hop, int win) {
+    const int pitch = FB == 8 ? RowPitch<8>::value : RowPitch<16>::value;
+    return sizeof(float) * (2 * FB * pitch + (FB - 1) * hop + win);
+}
 
 }  // namespace advh
 
@@ -325,7 +372,8 @@ extern "C" int advh_init(void) {
     const void* big[] = {(const void*)stft_fwd_kernel<16, 0>, (const void*)stft_fwd_kernel<8, 0>, (const void*)stft_fwd_kernel<16, 1>,
                          (const void*)stft_fwd_kernel<8, 1>, (const void*)istft_kernel<0, 16>,
                          (const void*)istft_kernel<2, 16>, (const void*)istft_kernel<2, 8>,
-                         (const void*)istft_kernel<1, 16>, (const void*)istft_kernel<0, 8>, (const void*)istft_kernel<1, 8>};
+                         (const void*)istft_kernel<1, 16>, (const void*)istft_kernel<0, 8>, (const void*)istft_kernel<1, 8>,
+                         (const void*)istft_kernel<3, 16>, (const void*)istft_kernel<3, 8>};
     for (const void* f : big)
         if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, maxlds) != hipSuccess) return ADVH_ELAUNCH;
     int rc = advh_init_rest();
@@ -399,7 +447,9 @@ static int launch_istft(int src, const float* a, const float* ph, const float* m
     if (!o0 && !o1) return ADVH_EINVAL;
     if (!o0) { which0 = 1; p0 = o1; nz = 1; }
     else if (!o1) { nz = 1; }
+    if (src == 1) p1 = nullptr;
     if (src == 2) nz = nbands;
+    else { if (nz == 1) p1 = nullptr; nz = 1; }      // mask-in and mask-out are two passes of one workgroup (p1 != NULL)
     const int nG = (NFFT / 2 + L - left + S * hop - 1) / (S * hop);
     dim3 grid(nG, B, nz);
 #define ISTFT_LAUNCH(SRC_, FB_)                                                                                          \
@@ -407,6 +457,7 @@ static int launch_istft(int src, const float* a, const float* ph, const float* m
                        mask, Fm, Tm, mode, which0, p0, p1, (long)ws, T, L, hop, win, R, window, (long)zstride)
     if (src == 0) { if (FB == 8) ISTFT_LAUNCH(0, 8); else ISTFT_LAUNCH(0, 16); }
     else if (src == 1) { if (FB == 8) ISTFT_LAUNCH(1, 8); else ISTFT_LAUNCH(1, 16); }
+    else if (src == 3) { if (FB == 8) ISTFT_LAUNCH(3, 8); else ISTFT_LAUNCH(3, 16); }
     else { if (FB == 8) ISTFT_LAUNCH(2, 8); else ISTFT_LAUNCH(2, 16); }
 #undef ISTFT_LAUNCH
     return hipGetLastError() == hipSuccess ? ADVH_OK : ADVH_ELAUNCH;
@@ -420,6 +471,14 @@ extern "C" int advh_istft_masked(const float* mag, const float* phase, const flo
     if (mode < 0 || mode > ADVH_MASK_LOG1P) return ADVH_EINVAL;
     if (mode == ADVH_MASK_NONE && wave_out) return ADVH_EINVAL;
     return launch_istft(0, mag, phase, mask, Fm, Tm, mode, wave_in, wave_out, wave_stride, B, T, L, hop, win, window, stream);
+}
+
+extern "C" int advh_istft_masked_c64(const float* spec, const float* mask, int Fm, int Tm, int mode, float* wave_in, float* wave_out,
+                                     int64_t wave_stride, int B, int T, int L, int hop, int win, const float* window,
+                                     advh_stream_t stream) {
+    if (!spec || !mask || wave_stride < L || Fm <= 0 || Tm <= 0 || Fm > NBIN || Tm > T) return ADVH_EINVAL;
+    if (mode != ADVH_MASK_LINEAR && mode != ADVH_MASK_LOG1P) return ADVH_EINVAL;
+    return launch_istft(3, spec, nullptr, mask, Fm, Tm, mode, wave_in, wave_out, wave_stride, B, T, L, hop, win, window, stream);
 }
 
 extern "C" int advh_istft_bandswap(const float* spec_a, const float* spec_b, int k0, int kw, int nbands, float* waves,
