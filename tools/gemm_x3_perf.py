@@ -11,8 +11,10 @@ def bench(name, M, K, N):
     w = torch.randn(N, K, generator=g) / K ** 0.5
     a = torch.randn(M + 1024, K, generator=g)
     res = []
-    for split in (False, True):
+    ref = None
+    for split, tile in ((False, G.TILE_128x128), (True, G.TILE_128x128)):
         p = G.plan_linear(M, w, torch.zeros(N), device=dev, split=split)
+        p.tile = tile
         A = (G.split_planes(a) if split else a.half()).to(dev)
         out = torch.empty(((2,) if split else ()) + (M, N), dtype=torch.float16, device=dev)
         for _ in range(3):
@@ -26,7 +28,14 @@ def bench(name, M, K, N):
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / n
-        res.append(f"{'x3 ' if split else 'f16'}: {ms * 1e3:8.1f} us {2.0 * M * N * K / ms / 1e9:7.1f} TF")
+        chk = ""
+        if split:
+            v = G.join_planes(out)
+            if ref is None:
+                ref = v
+            else:
+                chk = f" d={((v - ref).abs().max() / ref.abs().max()).item():.1e}"
+        res.append(f"{('x3 ' + G.TILE_NAMES[tile]) if split else 'f16'}: {ms * 1e3:8.1f} us {2.0 * M * N * K / ms / 1e9:7.1f} TF{chk}")
     print(f"{name:12s} M={M:7d} K={K:5d} N={N:5d} | " + " | ".join(res), flush=True)
 
 

@@ -128,12 +128,13 @@ def check(rc: int, what: str) -> None:
         raise AdvhError(f"{what}: {ERRORS.get(rc, rc)}")
 
 
-_inited = False
+_inited = set()
 
 
 def init() -> None:
-    """advh_init() on the current device (twiddle tables, LDS limits)."""
-    global _inited
-    if not _inited:
+    """advh_init() on the current device (twiddle tables, LDS limits); once per device of this process."""
+    import torch
+    dev = torch.cuda.current_device() if torch.cuda.is_available() else -1
+    if dev not in _inited:
         check(lib().advh_init(), "advh_init")
-        _inited = True
+        _inited.add(dev)

@@ -141,18 +141,24 @@ def join_planes(t: torch.Tensor) -> torch.Tensor:
 
 
 W8_RULE = int(os.environ.get("ADDVISOR_GEMM_W8_MIN_M", "0"))
+X3_SUPER_COLUMN_BYTES = int(os.environ.get("ADDVISOR_X3_SC_BYTES", "1600000"))
 SUPER_COLUMN_BYTES = int(os.environ.get("ADDVISOR_GEMM_SC_BYTES", "1600000"))   # +5-8 % on isolated QKV / FFN1 launches, +0.7 % in the pipeline
 
 
-def super_columns(N: int, Kp: int, M: int) -> int:
-    """Super-column width (in 128-column tiles) of the tile order: keep the weight slice in flight under
-    ``SUPER_COLUMN_BYTES`` when the whole weight would not stay resident in an XCD's 4 MiB L2; 0 = off."""
-    if SUPER_COLUMN_BYTES <= 0 or N <= 128:
+def super_columns(N: int, Kp: int, M: int, bn: int = 128, split: bool = False) -> int:
+    """Super-column width (in ``bn``-column tiles) of the tile order: keep the weight slice in flight under
+    ``SUPER_COLUMN_BYTES`` when the whole weight would not stay resident in an XCD's 4 MiB L2; 0 = off.  A split-format
+    weight is two fp16 planes (4 bytes per element)."""
+    bpe = 4 if split else 2
+    budget = X3_SUPER_COLUMN_BYTES if split else SUPER_COLUMN_BYTES
+    if budget <= 0 or N <= bn:
         return 0
-    tiles_n = (N + 127) // 128
-    if tiles_n * 128 * Kp * 2 <= 3 * 1024 * 1024:
+    tiles_n = (N + bn - 1) // bn
+    if tiles_n * bn * Kp * bpe <= 3 * 1024 * 1024:
         return 0
-    sc = min(tiles_n, SUPER_COLUMN_BYTES // (128 * Kp * 2))
+    sc = min(tiles_n, budget // (bn * Kp * bpe))
+    if split:
+        return max(1, sc)
     return sc if sc >= 4 else 0            # narrower super-columns re-read the activations too often (deep-K layers)
 
 
@@ -274,7 +280,7 @@ class GemmPlan:
         o_sB, o_sH, o_sW, _ = out
         d.plain_out = int(bool(d.plain and n_div_v >= N and phase[0] == 0 and n_sub <= 1 and tuple(window) == (0, Hg, 0, Wg)
                                and (Hg == 1 or o_sH == Wg * o_sW) and (M <= Hg * Wg or o_sB == Hg * Wg * o_sW)))
-        d.sc = super_columns(N, Kp, M)
+        d.sc = super_columns(N, Kp, M, 128, split)
         self.desc = d
         self.nsrc = len(sources)
         self.flops = 2.0 * M * N * K * nz          # algorithmic (unpadded) FLOPs of this launch
@@ -339,6 +345,8 @@ class GemmPlan:
             d.resid, d.resid_f32 = None, 0
         if stream is None:
             stream = torch.cuda.current_stream().cuda_stream
+        if self.split:                                     # the super-column width counts tiles of the chosen width
+            d.sc = super_columns(d.N, self.Kp, d.M, TILE_BN.get(self.tile, 128), True)
         if TUNER.active and not getattr(self, "_tuned", False):
             self._tune(d, stream)
         prof = PROFILE.enabled and self.tile not in (TILE_256x64, TILE_256x32)

@@ -520,12 +520,7 @@ static int launch_att_bwd(const void* qkv, const void* dctx, void* dqkv, int B, 
     constexpr int PA = TR ? 2 * ROWB : (D <= 64 ? 2 * ROWB + TRB : ROWB + TRB);
     const size_t lds = (size_t)(PA > 2 * TRB ? PA : 2 * TRB) * 2 + 3 * NKEY * 4;
     if (lds > 160 * 1024) return ADVH_EUNSUPPORTED;
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)attention_bwd_kernel<NT, D, TR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            return ADVH_ELAUNCH;
-        attr_done = true;
-    }
+    if (advh_ensure_lds((const void*)attention_bwd_kernel<NT, D, TR>) != ADVH_OK) return ADVH_ELAUNCH;
     hipLaunchKernelGGL((attention_bwd_kernel<NT, D, TR>), dim3(heads, B), dim3(256), lds, s, (const _Float16*)qkv, (const _Float16*)dctx,
                        (_Float16*)dqkv, T, H, dm, scale);
     return ADVH_LAUNCH_CHECK();

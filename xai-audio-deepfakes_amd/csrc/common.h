@@ -7,4 +7,21 @@
 int advh_init_rest();
 int advh_init_attention();   // attention.hip
 
+// Raise a kernel's dynamic-LDS limit to `bytes` once per (kernel, DEVICE): the attribute belongs to the device's copy of
+// the code object, and one process may drive several GPUs (a per-process "done" flag left the second device at 64 KiB).
+#include <mutex>
+#include <set>
+#include <utility>
+inline int advh_ensure_lds(const void* fn, int bytes = 160 * 1024) {
+    static std::mutex mu;
+    static std::set<std::pair<const void*, int>> done;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return ADVH_ELAUNCH;
+    std::lock_guard<std::mutex> lk(mu);
+    if (done.count({fn, dev})) return ADVH_OK;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return ADVH_ELAUNCH;
+    done.insert({fn, dev});
+    return ADVH_OK;
+}
+
 #define ADVH_LAUNCH_CHECK() (hipGetLastError() == hipSuccess ? ADVH_OK : ADVH_ELAUNCH)

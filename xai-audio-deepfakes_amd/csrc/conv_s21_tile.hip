@@ -144,12 +144,7 @@ extern "C" int advh_conv53s21_tile_f16(const advh_convs21_desc* d, advh_stream_t
     if (!d || !d->X || !d->W || !d->out_h || d->B <= 0 || d->Ho <= 0 || d->W_ <= 0) return ADVH_EINVAL;
     if (d->PHi < 2 || d->PWi < 1 || d->PHo < 0 || d->PWo < 0) return ADVH_EINVAL;
     if (d->act != ADVH_ACT_NONE && d->act != ADVH_ACT_LEAKY) return ADVH_EINVAL;
-    static bool attr = false;
-    if (!attr) {
-        if (hipFuncSetAttribute((const void*)conv53s21_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            return ADVH_ELAUNCH;
-        attr = true;
-    }
+    if (advh_ensure_lds((const void*)conv53s21_tile_kernel) != ADVH_OK) return ADVH_ELAUNCH;
     const long ntiles = (long)d->B * ((d->Ho + S21_TY - 1) / S21_TY) * ((d->W_ + S21_TX - 1) / S21_TX);
     const long grid = ntiles < 256 ? ntiles : 256;
     hipLaunchKernelGGL(conv53s21_tile_kernel, dim3((unsigned)grid), dim3(256), S21_WBYTES + 2 * S21_PCH * 16, (hipStream_t)stream, *d);

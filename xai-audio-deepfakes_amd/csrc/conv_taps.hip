@@ -359,12 +359,8 @@ extern "C" int advh_conv_taps_f16(const advh_taps_desc* d, int C, advh_stream_t 
     typedef void (*kern_t)(const advh_taps_desc);
     static const kern_t kerns[2][3] = {{conv_taps_kernel<32, 2>, conv_taps_kernel<32, 3>, conv_taps_kernel<32, 4>},
                                        {conv_taps_kernel<64, 2>, conv_taps_kernel<64, 2, 6>, conv_taps_kernel<64, 2, 8>}};   // 192 / 256 positions: six / eight wavefronts of two column tiles
-    static bool attr[2][3] = {{false, false, false}, {false, false, false}};
     const int ci = C == 64, ji = nj - 2;
-    if (!attr[ci][ji]) {
-        if (hipFuncSetAttribute((const void*)kerns[ci][ji], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return ADVH_ELAUNCH;
-        attr[ci][ji] = true;
-    }
+    if (advh_ensure_lds((const void*)kerns[ci][ji]) != ADVH_OK) return ADVH_ELAUNCH;
     const int ntiles = (d->M + tt - 1) / tt;
     const int per_cu = lds <= 40 * 1024 ? 4 : (lds <= 53 * 1024 ? 3 : (lds <= 80 * 1024 ? 2 : 1));
     int grid = 256 * per_cu;
@@ -378,13 +374,9 @@ extern "C" int advh_conv_taps2d_f16(const advh_taps2d_desc* d, int C, advh_strea
     if (C != 32 && C != 64) return ADVH_EUNSUPPORTED;
     if (d->act != ADVH_ACT_NONE && d->act != ADVH_ACT_LEAKY) return ADVH_EINVAL;
     const int lds = 9 * C * C * 2 + 2 * ((18 * 18 * (C / 8) + 63) / 64 * 64) * 16;
-    static bool attr[2] = {false, false};
     const int ci = C == 64;
     const void* fn = ci ? (const void*)conv_taps2d_kernel<64, 8> : (const void*)conv_taps2d_kernel<32>;
-    if (!attr[ci]) {
-        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return ADVH_ELAUNCH;
-        attr[ci] = true;
-    }
+    if (advh_ensure_lds(fn) != ADVH_OK) return ADVH_ELAUNCH;
     const long ntiles = (long)d->B * ((d->H + 15) / 16) * ((d->W_ + 15) / 16);
     const int per_cu = lds <= 80 * 1024 ? 2 : 1;
     long grid = 256L * per_cu;

@@ -157,13 +157,9 @@ extern "C" int advh_conv_wgrad2d_f16(const advh_wgrad2d_desc* d, int C, float* d
         return ADVH_EINVAL;
     if (C != 32 && C != 64) return ADVH_EUNSUPPORTED;
     const int lds = 2 * ((((18 * 18 * (C / 8) + 63) & ~63) + 256 * (C / 8)) * 16);
-    static bool attr[2] = {false, false};
     const int ci = C == 64;
     const void* fn = ci ? (const void*)conv_wgrad2d_kernel<64> : (const void*)conv_wgrad2d_kernel<32>;
-    if (!attr[ci]) {
-        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return ADVH_ELAUNCH;
-        attr[ci] = true;
-    }
+    if (advh_ensure_lds(fn) != ADVH_OK) return ADVH_ELAUNCH;
     const int grid = advh_conv_wgrad2d_parts(C, d->B, d->H, d->W_);
     hipStream_t s = (hipStream_t)stream;
     if (ci) hipLaunchKernelGGL(conv_wgrad2d_kernel<64>, dim3(grid), dim3(256), lds, s, *d);

@@ -60,21 +60,36 @@ template <int DIR> ADVH_HD void dft8(cf (&v)[8]) {
     v[3] = cadd(e3, o3); v[7] = csub(e3, o3);
 }
 
-// tw[k] = (cos(2*pi*k/1024), sin(2*pi*k/1024)), k in [0,1024)
-template <int DIR, int NS> ADVH_HD void fft512_pass_load(const float* re, const float* im, int lane,
-                                                         const cf* tw, cf (&v)[8]) {
+// tw[k] = (cos(2*pi*k/1024), sin(2*pi*k/1024)), k in [0,1024).
+// The pass twiddles of a lane depend on the lane only, not on the data: fft512_lane_twiddles fetches the 7 of pass NS
+// once (a wavefront transforms several frames; per-frame table loads from global memory were the longest dependent
+// chain of the STFT kernels), fft512_pass_load_tw consumes them.
+template <int NS> ADVH_HD void fft512_lane_twiddles(const cf* tw, int lane, cf (&twr)[7]) {
+    const int k = lane % NS;
+#pragma unroll
+    for (int r = 1; r < 8; ++r) twr[r - 1] = tw[(2 * r * k * (64 / NS)) & 1023];
+}
+
+template <int DIR, int NS> ADVH_HD void fft512_pass_load_tw(const float* re, const float* im, int lane, const cf (&twr)[7],
+                                                            cf (&v)[8]) {
 #pragma unroll
     for (int r = 0; r < 8; ++r) { int p = fidx(lane + 64 * r); v[r] = cf{re[p], im[p]}; }
     if (NS > 1) {
-        const int k = lane % NS;
 #pragma unroll
         for (int r = 1; r < 8; ++r) {
-            cf w = tw[(2 * r * k * (64 / NS)) & 1023];
+            cf w = twr[r - 1];
             if (DIR < 0) w.y = -w.y;
             v[r] = cmul(v[r], w);
         }
     }
     dft8<DIR>(v);
+}
+
+template <int DIR, int NS> ADVH_HD void fft512_pass_load(const float* re, const float* im, int lane,
+                                                         const cf* tw, cf (&v)[8]) {
+    cf twr[7];
+    fft512_lane_twiddles<NS>(tw, lane, twr);
+    fft512_pass_load_tw<DIR, NS>(re, im, lane, twr, v);
 }
 
 template <int NS> ADVH_HD void fft512_pass_store(float* re, float* im, int lane, const cf (&v)[8]) {

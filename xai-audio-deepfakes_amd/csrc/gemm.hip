@@ -1143,6 +1143,7 @@ int advh_init_rest() {
         return ADVH_ELAUNCH;
     X3_ATTR(128, 128, 2, 2) X3_ATTR(256, 64, 4, 1) X3_ATTR(256, 32, 4, 1)
 #undef X3_ATTR
+
     return ADVH_OK;
 }
 

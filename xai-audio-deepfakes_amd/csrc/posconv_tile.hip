@@ -190,11 +190,7 @@ extern "C" int advh_posconv_tile_f16(const advh_posconv_desc* d, advh_stream_t s
     const int lds = advh_posconv_tile_lds_bytes(Cg, d->T);
     if (lds < 0) return ADVH_EUNSUPPORTED;
     const void* fn = Cg == 48 ? (const void*)posconv_tile_kernel<6> : (const void*)posconv_tile_kernel<8>;
-    static bool attr[2] = {false, false};
-    if (!attr[Cg == 64]) {
-        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return ADVH_ELAUNCH;
-        attr[Cg == 64] = true;
-    }
+    if (advh_ensure_lds(fn) != ADVH_OK) return ADVH_ELAUNCH;
     const long tiles = (long)d->G * d->B;
     const long per_cu = lds <= 80 * 1024 ? 2 : 1;
     long grid = 256 * per_cu;

@@ -248,13 +248,9 @@ extern "C" int advh_resblock_pair_f16(const advh_resblock_desc* d, int C, advh_s
     const int nbuf = rb_nbuf(C, d->k, d->dil);
     const int lds = rb_lds(C, d->k, d->dil, nbuf);
     if (lds > 160 * 1024 || (d->k - 1) / 2 * 2 >= RB_TC / 2) return ADVH_EUNSUPPORTED;
-    static bool attr[2] = {false, false};
     const int ci = C == 64;
     const void* fn = ci ? (const void*)resblock_pair_kernel<64, 2> : (const void*)resblock_pair_kernel<32>;
-    if (!attr[ci]) {
-        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return ADVH_ELAUNCH;
-        attr[ci] = true;
-    }
+    if (advh_ensure_lds(fn) != ADVH_OK) return ADVH_ELAUNCH;
     const int TO = RB_TC - (d->k - 1);
     const int ntiles = (d->M + TO - 1) / TO;
     int grid = 256 * (lds <= 80 * 1024 ? 2 : 1);

@@ -18,35 +18,56 @@
 namespace advh {
 
 __device__ cf g_twiddle[1024];   // e^{+2 pi i k / 1024}
-static bool g_init_done = false;
+#ifdef ADVH_STAMPS                // diagnostic build only (make EXTRA=-DADVH_STAMPS): s_memtime at the phase boundaries of one workgroup
+__device__ long long g_stamps[16];
+#define STAMP(i) do { if (blockIdx.x == 3 && blockIdx.y == 5 && threadIdx.x == 0) g_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+static bool g_init_done[64] = {false};     // per device: twiddle table + dynamic-LDS limits live in each device's code object
+static bool init_done_here() { int dev = 0; return hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && g_init_done[dev]; }
 
 constexpr int NFFT = 1024;
 constexpr int NBIN = 513;
 // frames per workgroup: template parameter FB (16: 64/128-byte runs per bin, 90 KB LDS = 1 workgroup per CU;
 // 8: half the run length, 45 KB = 3 workgroups per CU).  g_stft_fb selects it (advh_set_option).
 static int g_stft_fb = 8;
-constexpr int THREADS = 256;
+constexpr int THREADS = 512;           // 8 wavefronts: one frame each at FB = 8, so a workgroup's transforms run side by side
 
 __device__ __forceinline__ void wave_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
 
-template <int DIR>
-__device__ __forceinline__ void fft512_wave(float* re, float* im, int lane) {
-    cf v[8];
-    fft512_pass_load<DIR, 1>(re, im, lane, g_twiddle, v);
-    wave_fence();
+// Per-lane constants of a wavefront's transforms, fetched once per wavefront (not per frame): the twiddles of the two
+// twiddled passes and of the real-transform glue (bins lane + 1 + 64 q).
+struct LaneTw { cf p8[7], p64[7], glue[4]; };
+__device__ __forceinline__ void load_lane_twiddles(int lane, LaneTw& t) {
+    fft512_lane_twiddles<8>(g_twiddle, lane, t.p8);
+    fft512_lane_twiddles<64>(g_twiddle, lane, t.p64);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) t.glue[q] = g_twiddle[lane + 1 + 64 * q];
+}
+
+// FROM_REGS: v already holds the lane's 8 inputs z[lane + 64 r] (the forward builds them straight from global memory),
+// so the first pass needs no LDS round trip; TO_REGS: the outputs y[lane + 64 r] stay in v (the inverse overlap-adds
+// them from registers), so the last pass stores nothing.  Each saves 16 ds_write + 16 ds_read per lane and frame.
+template <int DIR, bool FROM_REGS, bool TO_REGS>
+__device__ __forceinline__ void fft512_wave(float* re, float* im, int lane, const LaneTw& t, cf (&v)[8]) {
+    if (FROM_REGS) dft8<DIR>(v);
+    else { fft512_pass_load_tw<DIR, 1>(re, im, lane, t.p8, v); wave_fence(); }     // pass 1 has no twiddles (the argument is ignored)
     fft512_pass_store<1>(re, im, lane, v);
     wave_fence();
-    fft512_pass_load<DIR, 8>(re, im, lane, g_twiddle, v);
+    fft512_pass_load_tw<DIR, 8>(re, im, lane, t.p8, v);
     wave_fence();
     fft512_pass_store<8>(re, im, lane, v);
     wave_fence();
-    fft512_pass_load<DIR, 64>(re, im, lane, g_twiddle, v);
-    wave_fence();
-    fft512_pass_store<64>(re, im, lane, v);
-    wave_fence();
+    fft512_pass_load_tw<DIR, 64>(re, im, lane, t.p64, v);
+    if (!TO_REGS) {
+        wave_fence();
+        fft512_pass_store<64>(re, im, lane, v);
+        wave_fence();
+    }
 }
 
 // Row pitch of the LDS tile (words).  The spectrogram side of both kernels walks the tile TRANSPOSED -- lane -> (frame
@@ -95,7 +116,7 @@ __device__ __forceinline__ float mask_factor(float m, float M, int mode) {
 struct AdjArgs { const float* mask; float* dmask; int Fm, Tm, mode, which; };
 
 template <int FB, int ADJ>
-__global__ __launch_bounds__(THREADS) void stft_fwd_kernel(
+__global__ __launch_bounds__(THREADS, 4) void stft_fwd_kernel(
     const float* __restrict__ wave, long wave_stride, int n_in, int L, int hop, int win,
     const float* __restrict__ window, float* __restrict__ X, float* __restrict__ mag,
     float* __restrict__ phase, int T, AdjArgs adj) {
@@ -108,8 +129,13 @@ __global__ __launch_bounds__(THREADS) void stft_fwd_kernel(
     const int left = (NFFT - win) / 2;
     const int span = (FB - 1) * hop + win;
 
-    // 1. stage the samples the 16 frames touch (reflect padding of the L-sample clip, zero tail)
+    // 1. (ADJ only) stage the samples the frames touch, divided by the overlap-add envelope.  The plain forward has no
+    // staging phase: every wavefront loads its frame's samples straight into the registers of the first FFT pass
+    // (step 2) -- 16 independent loads per lane in flight at once; the staged version serialised them behind one
+    // s_waitcnt per loop iteration and a workgroup barrier (5.3 of a workgroup's 22 kcycles, in-kernel stamps).
+    STAMP(0);
     const float* w = wave + (long)b * wave_stride;
+    if (ADJ)
     for (int i = tid; i < span; i += THREADS) {
         int src = tA * hop + left + i - NFFT / 2;
         float v = 0.f;
@@ -131,26 +157,51 @@ __global__ __launch_bounds__(THREADS) void stft_fwd_kernel(
         }
         smp[i] = v;
     }
-    __syncthreads();
+    if (ADJ) __syncthreads();
+    STAMP(1);
 
     // 2. one wavefront per frame: build z[n] = x[2n] + i x[2n+1], FFT512, real-transform glue
+    LaneTw ltw;
+    load_lane_twiddles(lane, ltw);
     for (int f = wv; f < FB; f += THREADS / 64) {
         if (tA + f >= T) break;                       // wave-uniform
         float* rr = re + f * ROWP;
         float* ii = im + f * ROWP;
         const float* fs = smp + f * hop;
+        cf zv[8];                                     // z[n] = x[2n] + i x[2n+1], n = lane + 64 q: the first pass's inputs
+        if (ADJ) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            int n = lane + 64 * q;
-            int j0 = 2 * n - left, j1 = j0 + 1;
-            float a = 0.f, c = 0.f;
-            if (j0 >= 0 && j0 < win) a = window ? fs[j0] * window[j0] : fs[j0];
-            if (j1 >= 0 && j1 < win) c = window ? fs[j1] * window[j1] : fs[j1];
-            rr[fidx(n)] = a;
-            ii[fidx(n)] = c;
+            for (int q = 0; q < 8; ++q) {
+                const int n = lane + 64 * q;
+                const int j0 = 2 * n - left, j1 = j0 + 1;
+                float a = 0.f, c = 0.f;
+                if (j0 >= 0 && j0 < win) a = window ? fs[j0] * window[j0] : fs[j0];
+                if (j1 >= 0 && j1 < win) c = window ? fs[j1] * window[j1] : fs[j1];
+                zv[q] = cf{a, c};
+            }
+        } else {
+            const int s0 = (tA + f) * hop + left - NFFT / 2;      // clip sample under window position 0 (before reflection)
+            const int nmax = min(n_in, L);
+            float xa[8], xc[8], wa[8], wc[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {             // all loads first (predicated), arithmetic afterwards
+                const int n = lane + 64 * q;
+                const int j0 = 2 * n - left, j1 = j0 + 1;
+                int a0 = s0 + j0, a1 = s0 + j1;
+                if (a0 < 0) a0 = -a0;
+                if (a0 >= L) a0 = 2 * (L - 1) - a0;
+                if (a1 < 0) a1 = -a1;
+                if (a1 >= L) a1 = 2 * (L - 1) - a1;
+                const bool ok0 = j0 >= 0 && j0 < win && a0 >= 0 && a0 < nmax, ok1 = j1 >= 0 && j1 < win && a1 >= 0 && a1 < nmax;
+                xa[q] = ok0 ? w[a0] : 0.f;
+                xc[q] = ok1 ? w[a1] : 0.f;
+                wa[q] = (window && ok0) ? window[j0] : 1.f;
+                wc[q] = (window && ok1) ? window[j1] : 1.f;
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) zv[q] = cf{xa[q] * wa[q], xc[q] * wc[q]};
         }
-        wave_fence();
-        fft512_wave<-1>(rr, ii, lane);
+        fft512_wave<-1, true, false>(rr, ii, lane, ltw, zv);
         cf A[4], Bv[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -164,7 +215,7 @@ __global__ __launch_bounds__(THREADS) void stft_fwd_kernel(
         for (int q = 0; q < 4; ++q) {
             int k = lane + 1 + 64 * q;
             cf xk, xm;
-            rfft_post_pair(A[q], Bv[q], g_twiddle[k], xk, xm);
+            rfft_post_pair(A[q], Bv[q], ltw.glue[q], xk, xm);
             rr[fidx(k)] = xk.x; ii[fidx(k)] = xk.y;
             rr[fidx(512 - k)] = xm.x; ii[fidx(512 - k)] = xm.y;
         }
@@ -174,6 +225,7 @@ __global__ __launch_bounds__(THREADS) void stft_fwd_kernel(
         }
     }
     __syncthreads();
+    STAMP(2);
 
     // 3. coalesced epilogue: t fastest (16 frames = one 64 B / 128 B run per bin)
     const int nvalid = min(FB, T - tA);
@@ -209,6 +261,7 @@ __global__ __launch_bounds__(THREADS) void stft_fwd_kernel(
         if (mag) mag[o] = __builtin_sqrtf(fmaf(xr, xr, xi * xi));      // |X| <= 1024 max|x|: no overflow to guard against (hypotf's job)
         if (phase) phase[o] = atan2f(xi, xr);
     }
+    STAMP(3);
 }
 
 // ------------------------------------------------------------------------------------------ inverse
@@ -220,7 +273,7 @@ __global__ __launch_bounds__(THREADS) void stft_fwd_kernel(
 // spectrograms (hifigan.py:208-222, train_logReg_swapping.py:70-81): grid z = band, bins [Fm + z*Tm, Fm + (z+1)*Tm)
 // come from `phase` (the vocoded signal), all others from `mag` (the original); output z at out0 + z * out1_stride.
 template <int SRC, int FB>
-__global__ __launch_bounds__(THREADS) void istft_kernel(
+__global__ __launch_bounds__(THREADS, 3) void istft_kernel(
     const float* __restrict__ mag, const float* __restrict__ phase, const float* __restrict__ mask,
     int Fm, int Tm, int mode, int which0, float* __restrict__ out0, float* __restrict__ out1,
     long wave_stride, int T, int L, int hop, int win, int R, const float* __restrict__ window, long zstride) {
@@ -235,49 +288,68 @@ __global__ __launch_bounds__(THREADS) void istft_kernel(
     const int tA = g * S - (R - 1);                   // first frame it transforms (may be < 0)
     const int nacc = (FB - 1) * hop + win;
     const int npass = (SRC == 0 || SRC == 3) ? (out1 ? 2 : 1) : 1;
+    LaneTw ltw;
+    load_lane_twiddles(lane, ltw);
+    // tile loads: element idx = tid + it * THREADS -> (frame tl = idx % FB, bin k = idx / FB); SRC 0: (|X|, angle X),
+    // SRC 1 / 2 / 3: complex X; ldm = the mask value (0 outside the Fm x Tm crop: SURVEY.md D2/D3)
+    constexpr int NIT = (NBIN * FB + THREADS - 1) / THREADS;
+    float2 ld0[NIT];
+    float ldm[NIT];
+    bool valid[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int idx = tid + it * THREADS;
+        const int tl = idx & (FB - 1), k = idx / FB, t = tA + tl;
+        valid[it] = idx < NBIN * FB && t >= 0 && t < T;
+        ld0[it] = make_float2(0.f, 0.f);
+        ldm[it] = 0.f;
+        if (valid[it]) {
+            const long o = ((long)b * NBIN + k) * T + t;
+            if (SRC == 0) ld0[it] = make_float2(mag[o], phase[o]);
+            else if (SRC == 2) {
+                const int lo = Fm + (int)blockIdx.z * Tm;
+                ld0[it] = reinterpret_cast<const float2*>((k >= lo && k < lo + Tm) ? phase : mag)[o];
+            } else ld0[it] = reinterpret_cast<const float2*>(mag)[o];
+            if ((SRC == 0 || SRC == 3) && mode != ADVH_MASK_NONE && k < Fm && t < Tm) ldm[it] = mask[((long)b * Fm + k) * Tm + t];
+        }
+    }
     for (int pass = 0; pass < npass; ++pass) {
     const int which = which0 + pass;                  // 0: mask-in, 1: mask-out
     float* out = (SRC == 2 ? out0 + (long)blockIdx.z * zstride : (pass == 0 ? out0 : out1)) + (long)b * wave_stride;
     if (pass) __syncthreads();                        // the accumulator of the previous pass has been emitted
+    if (pass == 0) STAMP(4);
 
-    // 1. load the 513 x 16 tile, apply the mask and go polar -> cartesian
-    for (int idx = tid; idx < NBIN * FB; idx += THREADS) {
-        int tl = idx & (FB - 1), k = idx / FB, t = tA + tl;
-        float xr = 0.f, xi = 0.f;
-        if (t >= 0 && t < T) {
-            long o = ((long)b * NBIN + k) * T + t;
-            if (SRC == 1) {
-                float2 v = reinterpret_cast<const float2*>(mag)[o];
-                xr = v.x; xi = v.y;
-            } else if (SRC == 2) {
-                const int lo = Fm + (int)blockIdx.z * Tm;
-                float2 v = reinterpret_cast<const float2*>((k >= lo && k < lo + Tm) ? phase : mag)[o];
-                xr = v.x; xi = v.y;
-            } else if (SRC == 3) {
-                float2 v = reinterpret_cast<const float2*>(mag)[o];
-                float m = 0.f;
-                if (k < Fm && t < Tm) m = mask[((long)b * Fm + k) * Tm + t];
+    // 1. the 513 x FB tile: mask application, polar -> cartesian, into the LDS rows.  The global loads were issued before
+    // the pass loop (all of a thread's elements in flight at once) and serve both passes from registers.
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int idx = tid + it * THREADS;
+        if (idx >= NBIN * FB) break;
+        const int tl = idx & (FB - 1), k = idx / FB;
+        float xr = ld0[it].x, xi = ld0[it].y;
+        if (SRC == 3) {
+            float m = ldm[it];
+            if (which == 1) m = 1.f - m;
+            const float f = valid[it] ? mask_factor(m, __builtin_sqrtf(fmaf(xr, xr, xi * xi)), mode) : 0.f;
+            xr *= f; xi *= f;
+        } else if (SRC == 0) {
+            float a = ld0[it].x;
+            const float ph = ld0[it].y;
+            if (mode != ADVH_MASK_NONE) {
+                float m = ldm[it];
                 if (which == 1) m = 1.f - m;
-                const float f = mask_factor(m, __builtin_sqrtf(fmaf(v.x, v.x, v.y * v.y)), mode);
-                xr = v.x * f; xi = v.y * f;
-            } else {
-                float a = mag[o], ph = phase[o];
-                if (mode != ADVH_MASK_NONE) {
-                    float m = 0.f;
-                    if (k < Fm && t < Tm) m = mask[((long)b * Fm + k) * Tm + t];
-                    if (which == 1) m = 1.f - m;
-                    a = (mode == ADVH_MASK_LINEAR) ? m * a : fast_expm1(m * fast_log1p(a));
-                }
-                float s, c;
-                sincosf(ph, &s, &c);
-                xr = a * c; xi = a * s;
+                a = (mode == ADVH_MASK_LINEAR) ? m * a : fast_expm1(m * fast_log1p(a));
             }
+            float sn, cs;
+            sincosf(ph, &sn, &cs);
+            xr = valid[it] ? a * cs : 0.f; xi = valid[it] ? a * sn : 0.f;
         }
         re[tl * ROWP + fidx(k)] = xr;
         im[tl * ROWP + fidx(k)] = xi;
     }
     for (int i = tid; i < nacc; i += THREADS) acc[i] = 0.f;
     __syncthreads();
+    if (pass == 0) STAMP(5);
 
     // 2. one wavefront per frame: Hermitian glue, inverse FFT512, windowed overlap-add into LDS
     for (int f = wv; f < FB; f += THREADS / 64) {
@@ -298,24 +370,26 @@ __global__ __launch_bounds__(THREADS) void istft_kernel(
         for (int q = 0; q < 4; ++q) {
             int k = lane + 1 + 64 * q;
             cf zk, zm;
-            irfft_pre_pair(A[q], Bv[q], g_twiddle[k], zk, zm);
+            irfft_pre_pair(A[q], Bv[q], ltw.glue[q], zk, zm);
             rr[fidx(k)] = zk.x; ii[fidx(k)] = zk.y;
             rr[fidx(512 - k)] = zm.x; ii[fidx(512 - k)] = zm.y;
         }
         if (lane == 0) { rr[0] = 0.5f * (x0 + xn); ii[0] = 0.5f * (x0 - xn); }
         wave_fence();
-        fft512_wave<+1>(rr, ii, lane);
+        cf yv[8];
+        fft512_wave<+1, false, true>(rr, ii, lane, ltw, yv);          // y[lane + 64 q] stays in registers
         float* fa = acc + f * hop;
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             int n = lane + 64 * q;
             int j0 = 2 * n - left, j1 = j0 + 1;
-            float a = rr[fidx(n)] * (1.f / 512.f), c = ii[fidx(n)] * (1.f / 512.f);
+            float a = yv[q].x * (1.f / 512.f), c = yv[q].y * (1.f / 512.f);
             if (j0 >= 0 && j0 < win) atomicAdd(&fa[j0], window ? a * window[j0] : a);
             if (j1 >= 0 && j1 < win) atomicAdd(&fa[j1], window ? c * window[j1] : c);
         }
     }
     __syncthreads();
+    if (pass == 0) STAMP(6);
 
     // 3. emit the S complete hop-segments, divided by the window envelope, trimmed to [0, L)
     const int a0 = (R - 1) * hop;                     // first complete accumulator slot
@@ -334,6 +408,7 @@ __global__ __launch_bounds__(THREADS) void istft_kernel(
         }
         out[n] = env > 1e-11f ? acc[a] / env : 0.f;
     }
+    if (pass == 0) STAMP(7);
     }   // pass
 }
 
@@ -348,6 +423,10 @@ using namespace advh;
 
 extern "C" const char* advh_version(void) { return "addvisor_hip 0.1 (gfx950, wave64)"; }
 
+#ifdef ADVH_STAMPS
+extern "C" int advh_debug_stamps(long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(long long) * 16) == hipSuccess ? ADVH_OK : ADVH_ELAUNCH; }
+#endif
+
 extern "C" int advh_set_option(const char* name, int value) {
     if (!name) return ADVH_EINVAL;
     if (!strcmp(name, "stft_frames_per_workgroup")) {
@@ -361,7 +440,9 @@ extern "C" int advh_set_option(const char* name, int value) {
 extern "C" int advh_init(void) {
     static std::mutex mu;
     std::lock_guard<std::mutex> lk(mu);
-    if (g_init_done) return ADVH_OK;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return ADVH_ELAUNCH;
+    if (g_init_done[dev]) return ADVH_OK;
     cf host[1024];
     for (int k = 0; k < 1024; ++k) {
         host[k].x = (float)cos(2.0 * M_PI * k / 1024.0);
@@ -380,12 +461,12 @@ extern "C" int advh_init(void) {
     if (rc != ADVH_OK) return rc;
     rc = advh_init_attention();
     if (rc != ADVH_OK) return rc;
-    g_init_done = true;
+    g_init_done[dev] = true;
     return ADVH_OK;
 }
 
 static int check_frame_args(int B, int T, int L, int hop, int win) {
-    if (!g_init_done) return ADVH_ENOTINIT;
+    if (!init_done_here()) return ADVH_ENOTINIT;
     if (B <= 0 || L <= 0 || hop <= 0 || win <= 0 || win > NFFT || (win & 1) || T != 1 + L / hop) return ADVH_EINVAL;
     if (L <= NFFT / 2) return ADVH_EINVAL;           // reflect padding needs L > n_fft/2
     if (lds_bytes(g_stft_fb, hop, win) > 160 * 1024) return ADVH_EUNSUPPORTED;

@@ -165,12 +165,7 @@ extern "C" int advh_upconv21_tile_f16(const advh_upconv_desc* d, advh_stream_t s
     if (d->PHc < 1 || d->PWc < 1 || d->PHs < 1 || d->PWs < 1 || d->PHo < 0 || d->PWo < 0) return ADVH_EINVAL;
     if (d->Hc % 8) return ADVH_EUNSUPPORTED;                        // tiles are 16 output rows = 8 coarse rows
     if (d->act != ADVH_ACT_NONE && d->act != ADVH_ACT_LEAKY) return ADVH_EINVAL;
-    static bool attr = false;
-    if (!attr) {
-        if (hipFuncSetAttribute((const void*)upconv21_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            return ADVH_ELAUNCH;
-        attr = true;
-    }
+    if (advh_ensure_lds((const void*)upconv21_tile_kernel) != ADVH_OK) return ADVH_ELAUNCH;
     const long ntiles = (long)d->B * ((2 * d->Hc + 15) / 16) * ((d->W_ + 15) / 16);
     const long grid = ntiles < 256 ? ntiles : 256;
     hipLaunchKernelGGL(upconv21_tile_kernel, dim3((unsigned)grid), dim3(256), UC_WBYTES + 2 * UC_BUF, (hipStream_t)stream, *d);
