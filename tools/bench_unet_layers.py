@@ -9,7 +9,7 @@ from addvisor_hip.unet import HipUNet
 torch.set_grad_enabled(False)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 dev = torch.device("cuda:0")
-net = HipUNet(syn.unet_weights(), dev, fuse_up=os.environ.get("UNET_FUSE_UP", "1") != "0")
+net = HipUNet(syn.unet_weights(), dev, fuse_up=os.environ.get("UNET_FUSE_UP", "1") != "0", precision=os.environ.get("UNET_PRECISION", "f32"))
 mag = torch.rand(B, 513, 199, device=dev)
 net.forward(mag); torch.cuda.synchronize()
 ws = net._workspace(B, 512, 196)

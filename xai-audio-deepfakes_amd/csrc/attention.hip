@@ -252,9 +252,11 @@ __global__ __launch_bounds__(256, 2) void attention_tr_kernel(const _Float16* __
 // fp32-class instance: q, k, v and the context are plane pairs in the split format of device_math.h; both products cost
 // three MFMAs per fragment pair (hi*hi into the main accumulator, hi*lo + lo*hi into the cross accumulator, 2^-11),
 // the softmax is fp32 as before and the probabilities are split before O^T = V^T P^T.  K and V^T (hi and lo) of one
-// (clip, head) stay in LDS: 144 KB at T <= 256, head dim <= 64 => one workgroup per CU (attention is 4 % of the FLOPs).
+// (clip, head) stay in LDS: 144 KB at T <= 256, head dim <= 64 => one workgroup per CU (attention is 4 % of the FLOPs);
+// eight wavefronts share it, so the 13 query tiles of a 4 s clip take two rounds and each SIMD has a second wavefront to
+// issue while the first waits on LDS.
 template <int NT, int D>
-__global__ __launch_bounds__(256, 1) void attention_x3_kernel(const _Float16* __restrict__ qkv, long qkv_lo, _Float16* __restrict__ ctx,
+__global__ __launch_bounds__(512, 1) void attention_x3_kernel(const _Float16* __restrict__ qkv, long qkv_lo, _Float16* __restrict__ ctx,
                                                               long ctx_lo, int T, int H, int dm, float scale) {
     constexpr int NKEY = NT * 16, CH = D / 8, VP = NKEY + 64, NS = (NT + 1) / 2, KK = D / 32, DT = D / 16;
     extern __shared__ __attribute__((aligned(16))) _Float16 att_lds[];
@@ -266,13 +268,13 @@ __global__ __launch_bounds__(256, 1) void attention_x3_kernel(const _Float16* __
     const _Float16* base = qkv + (long)b * T * ld + head * dm;
     const int chm = dm / 8;
 
-    constexpr int NIT = (NKEY * CH + 255) / 256;
+    constexpr int NIT = (NKEY * CH + 511) / 512;
     for (int pl = 0; pl < 2; ++pl) {             // plane by plane: half the staging registers
         const _Float16* bp = base + (pl ? qkv_lo : 0);
         f16x8 kreg[NIT], vreg[NIT];
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            const int i = tid + it * 256, key = i / CH, c = i % CH;
+            const int i = tid + it * 512, key = i / CH, c = i % CH;
             kreg[it] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
             vreg[it] = kreg[it];
             if (i < NKEY * CH && key < T && c < chm) {
@@ -282,7 +284,7 @@ __global__ __launch_bounds__(256, 1) void attention_x3_kernel(const _Float16* __
         }
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            const int i = tid + it * 256, key = i / CH, c = i % CH;
+            const int i = tid + it * 512, key = i / CH, c = i % CH;
             if (i >= NKEY * CH) break;
             *(f16x8*)(Ks + pl * NKEY * D + key * D + ((c ^ (key & (CH - 1))) * 8)) = kreg[it];
 #pragma unroll
@@ -292,7 +294,7 @@ __global__ __launch_bounds__(256, 1) void attention_x3_kernel(const _Float16* __
     __syncthreads();
 
     const int fr = lane & 15, g = lane >> 4;
-    for (int qt = wv; qt * 16 < T; qt += 4) {
+    for (int qt = wv; qt * 16 < T; qt += 8) {            // 8 wavefronts (2 per SIMD): 13 query tiles at T = 199 take 2 rounds
         const int qrow = qt * 16 + fr;
         const int qr = qrow < T ? qrow : T - 1;
         f16x8 qh[KK], ql[KK];
@@ -428,10 +430,10 @@ extern "C" int advh_attention_split(const void* qkv, int64_t qkv_lo, void* ctx, 
     if (T > 256 || dm % 8 || dm > 64) return ADVH_EUNSUPPORTED;
     const int D = dm <= 32 ? 32 : 64;
     const float scale = 1.f / sqrtf((float)dm);
-    dim3 grid(heads, B), block(256);
+    dim3 grid(heads, B);
     hipStream_t s = (hipStream_t)stream;
     const int nt = (T + 15) / 16;
-#define ATTX(NT_, D_) hipLaunchKernelGGL((attention_x3_kernel<NT_, D_>), grid, block, att_x3_lds(NT_, D_), s, (const _Float16*)qkv, (long)qkv_lo, (_Float16*)ctx, (long)ctx_lo, T, H, dm, scale)
+#define ATTX(NT_, D_) hipLaunchKernelGGL((attention_x3_kernel<NT_, D_>), grid, dim3(512), att_x3_lds(NT_, D_), s, (const _Float16*)qkv, (long)qkv_lo, (_Float16*)ctx, (long)ctx_lo, T, H, dm, scale)
     if (D == 64) { if (nt <= 4) ATTX(4, 64); else if (nt <= 8) ATTX(8, 64); else if (nt <= 13) ATTX(13, 64); else ATTX(16, 64); }
     else { if (nt <= 4) ATTX(4, 32); else if (nt <= 8) ATTX(8, 32); else if (nt <= 13) ATTX(13, 32); else ATTX(16, 32); }
 #undef ATTX

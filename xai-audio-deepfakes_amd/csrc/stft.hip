@@ -273,7 +273,7 @@ __global__ __launch_bounds__(THREADS, 4) void stft_fwd_kernel(
 // spectrograms (hifigan.py:208-222, train_logReg_swapping.py:70-81): grid z = band, bins [Fm + z*Tm, Fm + (z+1)*Tm)
 // come from `phase` (the vocoded signal), all others from `mag` (the original); output z at out0 + z * out1_stride.
 template <int SRC, int FB>
-__global__ __launch_bounds__(THREADS, 3) void istft_kernel(
+__global__ __launch_bounds__(THREADS, 2) void istft_kernel(
     const float* __restrict__ mag, const float* __restrict__ phase, const float* __restrict__ mask,
     int Fm, int Tm, int mode, int which0, float* __restrict__ out0, float* __restrict__ out1,
     long wave_stride, int T, int L, int hop, int win, int R, const float* __restrict__ window, long zstride) {
