@@ -143,8 +143,10 @@ def main():
 
 
 # ------------------------------------------------------------------------------------------ the explanation step
-def run_explain(ctx, precision, steps, warmup):
-    """Time `steps` explanation steps in one precision; returns the numbers of that run."""
+def run_explain(ctx, precision, steps, warmup, vocoder=False):
+    """Time `steps` explanation steps in one precision; returns the numbers of that run.  `vocoder`: the north-star variant
+    in which both resyntheses are re-rendered by the HiFi-GAN V1 vocoder (mel front end + generator, fp16 operands) before
+    the classifier re-forward."""
     import torch
     from addvisor_hip import gemm as G, pipeline as P, synthetic as syn
     args, dev, rank, world, dist = ctx["args"], ctx["dev"], ctx["rank"], ctx["world"], ctx["dist"]
@@ -152,7 +154,13 @@ def run_explain(ctx, precision, steps, warmup):
     emb_sd = syn.embedder_weights(cfg)
     coef, icpt = syn.logreg_weights(cfg.hidden_size)
     unet_sd = syn.unet_weights()
-    pipe = P.ExplainPipeline(cfg, emb_sd, coef, icpt, unet_sd, dev, audio_length=AUDIO_LENGTH, streams=args.streams, precision=precision)
+    voc = None
+    if vocoder:
+        from addvisor_hip.hifigan import HipHifigan
+        hcfg = syn.HifiganConfig()
+        voc = HipHifigan(hcfg, syn.hifigan_weights(hcfg), dev)
+    pipe = P.ExplainPipeline(cfg, emb_sd, coef, icpt, unet_sd, dev, audio_length=AUDIO_LENGTH, streams=args.streams, precision=precision,
+                             vocoder=voc)
     B, L = args.batch, AUDIO_LENGTH * 16000
     n_batches = max(1, min(steps, 8))
     # clip indices are global and disjoint per rank: rank r, batch j -> clips [(j*world + r)*B, ...)
@@ -256,6 +264,12 @@ def explain_line(ctx):
         line[other] = {"value": round(o["value"], 2), "unit": "explanations/s", "ms_per_step": round(1e3 * o["elapsed"] / args.steps, 3),
                        "precision": prec_txt[other], "lmac": {k: round(v, 6) for k, v in o["metrics"].items()},
                        "pipeline_tflops": round(o["flops_step"] * args.steps / o["elapsed"] / 1e12, 1), "roofline": o["roofline"]}
+        v = run_explain(ctx, args.precision, 3, 1, vocoder=True)
+        line["explain_vocoder"] = {"workload": "the same step with both resyntheses re-rendered by the HiFi-GAN V1 vocoder (mel front end + generator, "
+                                               "128 clips x 251 frames per step, fp16 operands) before the classifier re-forward",
+                                   "value": round(v["value"], 2), "unit": "explanations/s", "ms_per_step": round(1e3 * v["elapsed"] / v["steps"], 3),
+                                   "steps": v["steps"], "dtype": f"{args.precision} (embedder, U-Net) + f16 (vocoder)",
+                                   "lmac": {k: round(x, 6) for k, x in v["metrics"].items()}}
         line["hifigan"] = bench_hifigan(ctx, 256, 5, 1)
         line["ig"] = bench_ig(ctx, 16, 64)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -89,9 +89,12 @@ def lmac_loss(xhat, X_stft_power, X_stft_phase, class_pred, w_raw, emb_sd, emb_c
 
 # ---- the unit of work of SURVEY.md §8d: one explanation per clip
 def explain(waves: torch.Tensor, emb_sd, emb_cfg, coef, intercept, unet_sd, audio_length=4,
-            domain="log1p", bn_batch=False) -> Dict[str, torch.Tensor]:
+            domain="log1p", bn_batch=False, vocoder=None) -> Dict[str, torch.Tensor]:
     """LMAC_metrics.py:117-157 with the D1-D5 resolutions of SURVEY.md §2.3:
-    STFT -> classifier(clean) -> U-Net(mask) -> mask-in / mask-out resynthesis -> classifier x2."""
+    STFT -> classifier(clean) -> U-Net(mask) -> mask-in / mask-out resynthesis -> classifier x2.
+    ``vocoder = (hifigan_sd, hifigan_cfg)``: the north-star variant "masked spectrogram -> HiFi-GAN vocoder -> classifier
+    re-forward": both resyntheses are re-rendered through the mel front end (hifigan.py:163-178) and the V1 generator
+    (hifigan.py:180), cropped / zero-padded to the clip length, before the classifier sees them."""
     X, mag, phase = S.compute_stft(waves, audio_length=audio_length)
     _, p_clean = W.classify(S.pad_or_crop(waves, int(audio_length * 16000)), emb_sd, emb_cfg, coef, intercept)
     mask = U.unet_forward(U.crop_for_unet(mag), unet_sd, bn_batch=bn_batch)[:, 0]
@@ -99,6 +102,11 @@ def explain(waves: torch.Tensor, emb_sd, emb_cfg, coef, intercept, unet_sd, audi
     rel, irr = S.apply_mask(mfull, mag, phase, domain)
     w_rel = S.compute_invert_stft(rel, audio_length=audio_length)
     w_irr = S.compute_invert_stft(irr, audio_length=audio_length)
+    if vocoder is not None:
+        from . import hifigan_ref as H
+        hsd, hcfg = vocoder
+        L = int(audio_length * 16000)
+        w_rel, w_irr = (S.pad_or_crop(H.generator(S.mel_spectrogram(w), hsd, hcfg)[:, 0], L) for w in (w_rel, w_irr))
     _, p_in = W.classify(w_rel, emb_sd, emb_cfg, coef, intercept)
     _, p_out = W.classify(w_irr, emb_sd, emb_cfg, coef, intercept)
     return dict(mag=mag, phase=phase, mask=mask, wave_in=w_rel, wave_out=w_irr,

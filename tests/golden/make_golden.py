@@ -206,6 +206,7 @@ def main():
     # ---- 7. the five LMAC metric formulas (LMAC_metrics.py:31-73) on a 64-triple table incl. ties at 0.5
     part_lmac_metrics()
     part_large()
+    part_unet5()
 
 
 def part_lmac_metrics():
@@ -236,7 +237,23 @@ def part_large():
          layer_absmax=np.array([h.abs().max().item() for h in hs[:10]]))
 
 
-PARTS = {"lmac_metrics": part_lmac_metrics, "large": part_large}
+def part_unet5():
+    """The reference's default clip length (audio_length = 5: T = 249 frames, 512 x 248 U-Net grid, SURVEY.md §8 sizes in
+    brackets), two clips: the reference UNet's mask (addvisor.py:12-84) on the reference STFT magnitude -- subsampled values,
+    the `mask > 0.5` count per clip and the SHA-256 of the index set."""
+    ce, apm, adv, lf = import_reference(syn.tiny_config(stable=False))
+    net = adv.UNet()
+    net.load_state_dict(syn.unet_weights(), strict=True)
+    net.eval()
+    _, mag5, _ = apm.AudioProcessor(audio_length=5).compute_stft(syn.make_clips(2, 80000, seed=71))
+    full = net(mag5[:, None, :512, :248])
+    idx = (full > 0.5).numpy().astype(np.uint8)
+    save("unet_5s.npz", shape=np.array(full.shape), mean=full.double().mean(), sub=full[:, 0, ::17, ::5],
+         gt_half=idx.reshape(2, -1).sum(1), idx_sha256=np.frombuffer(hashlib.sha256(idx.tobytes()).digest(), dtype=np.uint8),
+         band=int(((full - 0.5).abs() < 1e-3).sum()), closest=float((full - 0.5).abs().min()))
+
+
+PARTS = {"lmac_metrics": part_lmac_metrics, "large": part_large, "unet5": part_unet5}
 
 
 if __name__ == "__main__":

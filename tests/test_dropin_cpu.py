@@ -230,3 +230,23 @@ def test_logreg_trainer_and_eer(tmp_path):
         runtime.reset()
     (tmp_path / "m.txt").write_text("a.wav,x\nb.wav,y,z\n")
     assert T.find_all_files(str(tmp_path / "m.txt")) == ["a.wav", "b.wav"]
+
+
+def test_bench_self_launch_starts_ranks_and_propagates_failure():
+    """`python bench.py --gpus N` without a launcher must start N ranks itself (round 1 silently measured one GPU).  Without a
+    GPU every rank refuses to run ("bench.py needs a GPU"), which must surface as a non-zero exit of the parent -- and the
+    message proves that two ranks with WORLD_SIZE = 2 were started and that the parent itself never touched the GPU."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if torch.cuda.is_available():
+        pytest.skip("CPU-only check")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline",
+                        "--master-port", str(33000 + os.getpid() % 2000)], capture_output=True, text=True, timeout=240)
+    assert r.returncode != 0
+    out = r.stdout + r.stderr
+    assert out.count("bench.py needs a GPU") >= 1 and "--gpus 2 but WORLD_SIZE" not in out
+    # under a launcher with the wrong world size it refuses
+    env = dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode != 0 and "--gpus 2 but WORLD_SIZE=3" in (r.stdout + r.stderr)

@@ -145,3 +145,46 @@ def test_hip_graph_replay_matches_eager(gpu_device):
             assert torch.equal(eager[k], replay[k]), k
     short = syn.make_clips(3, 9000, seed=93).to(gpu_device)                 # ragged input: zero-padded to the clip length
     assert torch.equal(pipe.explain(short)["predictions"], pipe.explain_graphed(short)["predictions"])
+
+
+def test_explain_with_v1_vocoder_80_mels(gpu_device):
+    """north_star: "masked spectrogram -> HiFi-GAN vocoder -> classifier re-forward" with the real V1 generator on 80 mel
+    bands (the tiny-generator test above covers the plumbing): 1 s clips, against the oracle run with the same vocoder step
+    (oracle/lmac_ref.explain(vocoder=...)).  Stated tolerances: vocoded waveforms 2e-2 (the HiFi-GAN tolerance on top of the
+    resynthesis), probabilities TOL_PROB."""
+    from addvisor_hip.hifigan import HipHifigan
+    cfg, hcfg = syn.tiny_config(False), syn.HifiganConfig()
+    emb_sd, unet_sd, hsd = syn.embedder_weights(cfg), syn.unet_weights(), syn.hifigan_weights(hcfg)
+    coef, icpt = syn.logreg_weights(cfg.hidden_size)
+    w = syn.make_clips(2, 16000, seed=79)
+    pipe = P.ExplainPipeline(cfg, emb_sd, coef, icpt, unet_sd, gpu_device, audio_length=1, vocoder=HipHifigan(hcfg, hsd, gpu_device))
+    out = pipe.explain(w.to(gpu_device), keep=True)
+    ref = lmac_ref.explain(w, emb_sd, cfg, coef, icpt, unet_sd, audio_length=1, vocoder=(hsd, hcfg))
+    for key in ("wave_in", "wave_out"):
+        err = (out[key].cpu() - ref[key]).abs().max().item()
+        print(key, "vocoded max err", err)
+        assert err <= 2e-2
+    for k in ("predictions", "theta_out", "masked_predictions"):
+        err = (out[k].cpu() - ref[k]).abs().max().item()
+        print(k, "max err", err)
+        assert err <= TOL_PROB, k
+
+
+@pytest.mark.parametrize("B,n", [(1, 16000), (3, 11111), (2, 20001)])
+def test_explain_edge_shapes_f32(gpu_device, B, n):
+    """Ragged inputs of the loop body (LMAC_metrics.py:117-157 feeds whatever the loader returns): a single clip, clips
+    shorter than audio_length (zero-padded tail, audioprocessor.py:83-98) and longer (cropped), odd sample counts; fp32-class
+    mode against the oracle: probabilities 1e-4, mask 2e-5, mask indices equal, waveforms 5e-5."""
+    cfg = syn.tiny_config(True)
+    emb_sd, unet_sd = syn.embedder_weights(cfg), syn.unet_weights()
+    coef, icpt = syn.logreg_weights(cfg.hidden_size)
+    pipe = P.ExplainPipeline(cfg, emb_sd, coef, icpt, unet_sd, gpu_device, audio_length=1, precision="f32")
+    w = syn.make_clips(B, n, seed=200 + n)
+    out = pipe.explain(w.to(gpu_device), keep=True)
+    ref = lmac_ref.explain(w, emb_sd, cfg, coef, icpt, unet_sd, audio_length=1)
+    for k in ("predictions", "theta_out", "masked_predictions"):
+        assert out[k].shape == (B, 1) and (out[k].cpu() - ref[k]).abs().max().item() <= 1e-4, k
+    assert (out["mask"].cpu() - ref["mask"]).abs().max().item() <= 2e-5
+    assert torch.equal(out["mask"].cpu() > 0.5, ref["mask"] > 0.5)
+    assert (out["wave_in"].cpu() - ref["wave_in"]).abs().max().item() <= 5e-5
+    assert (out["wave_out"].cpu() - ref["wave_out"]).abs().max().item() <= 5e-5

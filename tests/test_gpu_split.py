@@ -183,3 +183,22 @@ def test_split_unet_full_size_exact_indices(gpu_device, golden):
     assert (mask[0, ::17, ::5].cpu() - torch.from_numpy(g["full_sub"])).abs().max().item() <= TOL_MASK
     single = net.forward(mag[:1].contiguous())
     assert torch.equal(single[0], mask[0])                    # batch invariance, bit-exact
+
+
+def test_split_unet_5s_exact_indices(gpu_device, golden):
+    """The reference's default clip length (5 s: 512 x 248 grid), two clips, whole HIP path (STFT kernel -> fp32-class U-Net):
+    `mask > 0.5` counts and SHA-256 of the reference's own index set (tests/golden/unet_5s.npz; its closest value to 0.5 is
+    1.6e-5 away)."""
+    sd = syn.unet_weights()
+    net = HipUNet(sd, gpu_device, precision="f32")
+    w = syn.make_clips(2, 80000, seed=71)
+    _, mag, _ = ops.stft_forward(w.to(gpu_device), 80000, want_complex=False, want_phase=False)
+    mask = net.forward(mag)
+    assert tuple(mask.shape) == (2, 512, 248)
+    g = golden("unet_5s.npz")
+    err = (mask[:, ::17, ::5].cpu() - torch.from_numpy(g["sub"])).abs().max().item()
+    idx = (mask > 0.5).cpu().numpy().astype(np.uint8)[:, None]
+    print(f"f32 mode 5 s: max err on the subsampled mask {err:.3e}; counts {idx.reshape(2, -1).sum(1).tolist()} (reference {g['gt_half'].tolist()})")
+    assert err <= TOL_MASK
+    assert idx.reshape(2, -1).sum(1).tolist() == g["gt_half"].tolist()
+    assert hashlib.sha256(idx.tobytes()).digest() == g["idx_sha256"].tobytes()

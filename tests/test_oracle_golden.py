@@ -124,6 +124,20 @@ def test_unet(golden):
     assert hashlib.sha256(idx.tobytes()).digest() == g["full_idx_sha256"].tobytes()   # bit-exact mask indices
 
 
+def test_unet_5s_golden(golden):
+    """Reference default length (audio_length = 5 -> 512 x 248 grid), two clips: oracle mask and `mask > 0.5` index set vs the
+    reference's own (tests/golden/make_golden.py unet5)."""
+    g = golden("unet_5s.npz")
+    sd = syn.unet_weights()
+    _, mag, _ = signal_ref.compute_stft(syn.make_clips(2, 80000, seed=71), audio_length=5)
+    full = unet_ref.unet_forward(unet_ref.crop_for_unet(mag), sd)
+    assert tuple(full.shape) == tuple(g["shape"])
+    close(full[:, 0, ::17, ::5], g["sub"], 1e-5)
+    idx = (full > 0.5).numpy().astype(np.uint8)
+    assert idx.reshape(2, -1).sum(1).tolist() == g["gt_half"].tolist()
+    assert hashlib.sha256(idx.tobytes()).digest() == g["idx_sha256"].tobytes()
+
+
 def test_lmac_loss(golden):
     g = golden("lmac_loss.npz")
     cfg = syn.tiny_config()
