@@ -21,8 +21,10 @@ fp16-operand mode is measured right after it and reported under `"f16"`.  `--pre
 FLOPs of its launches / their device time, measured with HIP events recorded on the launch stream inside the timed
 steps.  `cpu_baseline` times the CPU oracle (plain torch, the reference arithmetic) on a bounded sample of the same
 workload on this host's cores (rank 0, N = 1 only).  The default N = 1 invocation also measures BASELINE config 3
-(`"hifigan"`: HiFi-GAN V1, 256 x 251 mel frames) and config 5's per-GPU share (`"ig"`: IntegratedGradients, 50 steps x
-16 clips, wav2vec2-large) and appends them as extra keys; `--workload hifigan|ig` runs one of them as the headline.
+(`"hifigan"`: HiFi-GAN V1, 256 x 251 mel frames), config 5's per-GPU share (`"ig"`: IntegratedGradients, 50 steps x
+16 clips, wav2vec2-large), the vocoder variant of the step (`"explain_vocoder"`) and one rank's data-set loop of config 4
+with the PCIe upload inside the timed region (`"dataset"`: 4 133 clips from pinned host memory, ragged last batch) and
+appends them as extra keys; `--workload hifigan|ig|dataset` runs one of them as the headline.
 """
 import argparse
 import json
@@ -50,7 +52,7 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=BATCH)
-    ap.add_argument("--workload", choices=("explain", "hifigan", "ig"), default="explain")
+    ap.add_argument("--workload", choices=("explain", "hifigan", "ig", "dataset"), default="explain")
     ap.add_argument("--precision", choices=("f32", "f16"), default="f32", help="headline precision of the explain workload")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (f16 / hifigan / ig keys)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -134,6 +136,12 @@ def main():
         line = hifigan_line(ctx, bench_hifigan(ctx, args.batch if args.batch != BATCH else 256, args.steps, args.warmup))
     elif args.workload == "ig":
         line = ig_line(ctx, bench_ig(ctx, 16, 64))
+    elif args.workload == "dataset":
+        r = bench_dataset(ctx, args.precision)
+        line = {"metric": "explanations/sec over a host-resident data set (PCIe upload included)", "value": r["value"], "unit": "explanations/s",
+                "n_gpus": 1, "steps": 1, "warmup": 1, "ms_per_step": round(1e3 * r["seconds"], 1), "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": args.precision, "data": "synthetic", "config": {"workload": r["workload"]}, "lmac": r["lmac"],
+                "cpu_baseline": None}
     else:
         line = explain_line(ctx)
     if rank == 0:
@@ -270,6 +278,7 @@ def explain_line(ctx):
                                    "value": round(v["value"], 2), "unit": "explanations/s", "ms_per_step": round(1e3 * v["elapsed"] / v["steps"], 3),
                                    "steps": v["steps"], "dtype": f"{args.precision} (embedder, U-Net) + f16 (vocoder)",
                                    "lmac": {k: round(x, 6) for k, x in v["metrics"].items()}}
+        line["dataset"] = bench_dataset(ctx, args.precision)
         line["hifigan"] = bench_hifigan(ctx, 256, 5, 1)
         line["ig"] = bench_ig(ctx, 16, 64)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -277,6 +286,61 @@ def explain_line(ctx):
         emb_sd, coef, icpt, unet_sd = head["weights"]
         line["cpu_baseline"] = cpu_baseline(cfg, emb_sd, coef, icpt, unet_sd, args.cpu_clips, L, args.cpu_threads, args.cpu_repeats)
     return line
+
+
+# ------------------------------------------------------------------------------------------ BASELINE config 4 (one GPU's loop)
+def bench_dataset(ctx, precision, n_clips=4133, pool=512):
+    """The dataset loop of LMAC_metrics.run_addvisor_metrics (LMAC_metrics.py:117-172) as one rank of config 4 runs it:
+    clips live in HOST memory (pinned), every batch of 64 is uploaded over PCIe on a copy stream while the previous batch
+    computes (two device buffers), the last batch is ragged (n_clips % 64 != 0), the per-clip probabilities are gathered and
+    the five metrics reduced at the end.  The rate INCLUDES the upload -- unlike the headline, whose batches are resident."""
+    import torch
+    from addvisor_hip import pipeline as P, synthetic as syn
+    args, dev, rank, world = ctx["args"], ctx["dev"], ctx["rank"], ctx["world"]
+    cfg = syn.base_config()
+    coef, icpt = syn.logreg_weights(cfg.hidden_size)
+    pipe = P.ExplainPipeline(cfg, syn.embedder_weights(cfg), coef, icpt, syn.unet_weights(), dev, audio_length=AUDIO_LENGTH, precision=precision)
+    B, L = BATCH, AUDIO_LENGTH * 16000
+    host = syn.make_clips(pool, L, first=rank * pool).pin_memory()            # the "files": cycled through to reach n_clips
+    idx = P.shard_indices(n_clips * world, rank, world)                        # this rank's contiguous block of the data set
+    starts = list(range(idx.start, idx.stop, B))
+    bufs = [torch.empty(B, L, device=dev), torch.empty(B, L, device=dev)]
+    copy_s, cur = torch.cuda.Stream(device=dev), torch.cuda.current_stream()
+    ready = [torch.cuda.Event(), torch.cuda.Event()]
+    freed = [torch.cuda.Event(), torch.cuda.Event()]
+
+    def run():
+        probs = []
+        for j, s0 in enumerate(starts):
+            n = min(B, idx.stop - s0)
+            k = j & 1
+            off = (s0 * 7) % (pool - B)
+            with torch.cuda.stream(copy_s):
+                if j >= 2:
+                    copy_s.wait_event(freed[k])                                # the batch that used this buffer has been consumed
+                bufs[k][:n].copy_(host[off:off + n], non_blocking=True)
+                ready[k].record(copy_s)
+            cur.wait_event(ready[k])
+            out = pipe.explain(bufs[k][:n])
+            freed[k].record(cur)
+            probs.append(torch.cat([out["predictions"], out["theta_out"], out["masked_predictions"]], 1))
+        allp = torch.cat(probs, 0)
+        return P.lmac_metrics(allp[:, 0].contiguous(), allp[:, 1].contiguous(), allp[:, 2].contiguous())
+
+    pipe.explain(bufs[0]); pipe.explain(bufs[0][:(idx.stop - idx.start) % B or B])     # build both workspaces (full and ragged batch) outside the timed region
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    metrics = run()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    n_local = idx.stop - idx.start
+    out = {"workload": f"BASELINE config 4 as one rank runs it: {n_local} clips x 4 s from pinned host memory in batches of {B} (last batch {n_local % B or B}), "
+                       "upload overlapped on a copy stream, LMAC metrics at the end; wav2vec2-base + U-Net",
+           "value": round(n_local / dt, 1), "unit": "explanations/s (PCIe upload included)", "seconds": round(dt, 3), "clips": n_local, "dtype": precision,
+           "upload_GB": round(n_local * L * 4 / 1e9, 3), "lmac": {k: round(v, 6) for k, v in metrics.items()}}
+    del pipe, bufs, host
+    torch.cuda.empty_cache()
+    return out
 
 
 # ------------------------------------------------------------------------------------------ BASELINE config 3

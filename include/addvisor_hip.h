@@ -371,7 +371,8 @@ int advh_layernorm_split(const void* in, int in_is_f32, int64_t in_ld, int64_t i
                          int64_t out_lo, int M, int C, float eps, int gelu, advh_stream_t stream);
 int advh_posconv_gather_split(const float* h, void* xg, int64_t xg_lo, int B, int T, int H, int G, int K, int pad_left,
                               advh_stream_t stream);
-/* softmax(Q K^T / sqrt(d)) V on split q | k | v -> split ctx; T <= 256, head dim <= 64 (a multiple of 8). */
+/* softmax(Q K^T / sqrt(d)) V on split q | k | v -> split ctx; T <= 256, head dim a multiple of 8 up to 128 (above 64 the keys
+ * stream through LDS in blocks with an online softmax: XLS-R's head dim 120). */
 int advh_attention_split(const void* qkv, int64_t qkv_lo, void* ctx, int64_t ctx_lo, int B, int T, int H, int heads,
                          advh_stream_t stream);
 int advh_unet_stem_split(const float* mag, int Fq, int Tq, int B, int H, int W, const float* wgt, const float* bias,

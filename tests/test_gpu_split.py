@@ -202,3 +202,33 @@ def test_split_unet_5s_exact_indices(gpu_device, golden):
     assert err <= TOL_MASK
     assert idx.reshape(2, -1).sum(1).tolist() == g["gt_half"].tolist()
     assert hashlib.sha256(idx.tobytes()).digest() == g["idx_sha256"].tobytes()
+
+
+@pytest.mark.parametrize("T,heads,dm", [(199, 3, 64), (49, 2, 32), (17, 2, 16), (199, 2, 120), (249, 1, 128), (113, 2, 72), (40, 2, 120)])
+def test_split_attention_kernel(gpu_device, T, heads, dm):
+    """advh_attention_split (softmax(Q K^T / sqrt(d)) V, modeling_wav2vec2.py:438-548) against fp64 on split-format q | k | v:
+    whole-clip K / V^T in LDS for head dims <= 64, key blocks of 112 with an online softmax above (XLS-R's 120).
+    Stated tolerance: 5e-6 of max|ctx|."""
+    _lib.init()
+    B, H = 2, heads * dm
+    g = torch.Generator().manual_seed(T + dm)
+    qkv = rnd(g, B * T, 3 * H) * 1.5
+    planes = G.split_planes(qkv).to(gpu_device)
+    ctx = torch.zeros(2, B * T, H, dtype=torch.float16, device=gpu_device)
+    rc = _lib.lib().advh_attention_split(planes.data_ptr(), planes.stride(0), ctx.data_ptr(), ctx.stride(0), B, T, H, heads,
+                                        torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    x = G.join_planes(planes.cpu()).double().view(B, T, 3, heads, dm)      # what the kernel actually saw
+    q, k, v = (x[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+    ref = (torch.softmax(q @ k.transpose(-1, -2) / dm ** 0.5, -1) @ v).permute(0, 2, 1, 3).reshape(B * T, H)
+    e = rel(G.join_planes(ctx), ref)
+    print(f"split attention T={T} heads={heads} dm={dm}: rel {e:.2e}")
+    assert e <= TOL_KERNEL
+
+
+def test_split_xlsr_shaped_embedder(gpu_device):
+    """The reference's own embedder family (XLS-R-2B: head dim 120, layer-norm feature extractor, pre-LN encoder) at reduced
+    width / depth in the fp32-class mode, 3 s clips (149 frames: two key blocks in the streaming attention)."""
+    cfg = syn.tiny_config(True, hidden_size=240, num_attention_heads=2, intermediate_size=480,
+                          num_conv_pos_embedding_groups=2, num_hidden_layers=10)
+    _embedder_case(cfg, syn.make_clips(2, 48000, seed=33), gpu_device)

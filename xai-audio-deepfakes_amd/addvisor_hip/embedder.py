@@ -85,8 +85,6 @@ class HipEmbedder:
         if self.precision not in ("f16", "f32"):
             raise ValueError("precision must be 'f16' or 'f32'")
         self.split = self.precision == "f32"
-        if self.split and cfg.head_dim > 64:
-            raise ValueError("the fp32-class attention kernel supports head dims up to 64")
         self.sd = {k: v.detach().float() for k, v in sd.items()}
         if cfg.conv_kernel[0] != 10 or cfg.conv_stride[0] != 5:
             raise ValueError("feature-encoder layer 0 must be Conv1d(k=10, stride=5)")

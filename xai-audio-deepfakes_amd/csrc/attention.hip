@@ -382,6 +382,156 @@ __global__ __launch_bounds__(512, 1) void attention_x3_kernel(const _Float16* __
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// fp32-class attention for head dims 72 .. 128 (XLS-R-2B, the reference's own embedder: 1920 / 16 heads = 120): K and V^T of a
+// whole clip in both planes do not fit 160 KB at D = 128, so the keys stream through LDS in blocks of NTB * 16 with an online
+// softmax (running row maximum m and sum l in the log2 domain; O rescaled by 2^(m_old - m_new) when a block raises the
+// maximum).  Eight wavefronts = eight query tiles per round; a 4 s clip (13 tiles) takes two rounds, each re-staging the
+// blocks (the price of keeping one query tile's state per wavefront: 64 accumulator registers for O at D = 128).
+template <int NTB, int D>
+__global__ __launch_bounds__(512, 1) void attention_x3_stream_kernel(const _Float16* __restrict__ qkv, long qkv_lo, _Float16* __restrict__ ctx,
+                                                                     long ctx_lo, int T, int H, int dm, float scale) {
+    constexpr int KB = NTB * 16, CH = D / 8, VP = KB + 64, NS = (NTB + 1) / 2, KK = D / 32, DT = D / 16;
+    extern __shared__ __attribute__((aligned(16))) _Float16 att_lds[];
+    _Float16* Ks = att_lds;                      // [2][KB * D]
+    _Float16* Vt = att_lds + 2 * KB * D;         // [2][D * VP]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int head = blockIdx.x, b = blockIdx.y;
+    const long ld = 3L * H;
+    const _Float16* base = qkv + (long)b * T * ld + head * dm;
+    const int chm = dm / 8;
+    const int fr = lane & 15, g = lane >> 4;
+    const int nqt = (T + 15) / 16, nblk = (T + KB - 1) / KB;
+    constexpr int NIT = (KB * CH + 511) / 512;
+
+    for (int q0 = 0; q0 < nqt; q0 += 8) {
+        const int qt = q0 + wv;
+        const bool live = qt < nqt;                  // wave-uniform; idle wavefronts still take part in staging and barriers
+        const int qrow = qt * 16 + fr;
+        const int qr = qrow < T ? qrow : T - 1;
+        f16x8 qh[KK], ql[KK];
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+            const bool in = live && kk * 4 + g < chm;
+            qh[kk] = in ? *(const f16x8*)(base + (long)qr * ld + kk * 32 + g * 8) : f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            ql[kk] = in ? *(const f16x8*)(base + qkv_lo + (long)qr * ld + kk * 32 + g * 8) : f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+        float m_run = -INFINITY, l_run = 0.f;
+        f32x4 om[DT], ox[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) { om[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; ox[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+        for (int blk = 0; blk < nblk; ++blk) {
+            const int k0 = blk * KB;
+            __syncthreads();                         // every wavefront is done with the previous block
+            for (int pl = 0; pl < 4; ++pl) {         // K hi, K lo, V hi, V lo: one tensor plane at a time (staging registers)
+                const bool isv = pl >= 2;
+                const _Float16* bp = base + ((pl & 1) ? qkv_lo : 0) + (isv ? 2 * H : H);
+                f16x8 reg[NIT];
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    const int i = tid + it * 512, key = i / CH, c = i % CH;
+                    reg[it] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                    if (i < KB * CH && k0 + key < T && c < chm) reg[it] = *(const f16x8*)(bp + (long)(k0 + key) * ld + c * 8);
+                }
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    const int i = tid + it * 512, key = i / CH, c = i % CH;
+                    if (i >= KB * CH) break;
+                    if (!isv) *(f16x8*)(Ks + (pl & 1) * KB * D + key * D + ((c ^ (key & (CH - 1))) * 8)) = reg[it];
+                    else {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) Vt[(pl & 1) * D * VP + (c * 8 + j) * VP + (c & 7) * 8 + key] = reg[it][j];
+                    }
+                }
+            }
+            __syncthreads();
+            if (!live) continue;
+            f32x4 s[NTB];
+#pragma unroll
+            for (int kt = 0; kt < NTB; ++kt) {
+                f32x4 sm = f32x4{0.f, 0.f, 0.f, 0.f}, sx = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kk = 0; kk < KK; ++kk) {
+                    const int key = kt * 16 + fr, c = kk * 4 + g;
+                    const int o = key * D + ((c ^ (key & (CH - 1))) * 8);
+                    const f16x8 kh = *(const f16x8*)(Ks + o), kl = *(const f16x8*)(Ks + KB * D + o);
+                    sx = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, ql[kk], sx, 0, 0, 0);
+                    sm = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, qh[kk], sm, 0, 0, 0);
+                    sx = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl, qh[kk], sx, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s[kt][r] = fmaf(sx[r], SPLIT_LO_INV, sm[r]);
+                if ((kt & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+            }
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < NTB; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = (k0 + kt * 16 + g * 4 + r < T) ? s[kt][r] * (scale * LOG2E) : -INFINITY;
+                    s[kt][r] = v;
+                    mx = fmaxf(mx, v);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run, mx);     // finite: every block holds at least one key < T
+            const float alpha = exp2f(m_run - m_new); // 0 for the first block (m_run = -inf)
+            float sum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < NTB; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const float e = exp2f(s[kt][r] - m_new); s[kt][r] = e; sum += e; }
+            sum += __shfl_xor(sum, 16, 64);
+            sum += __shfl_xor(sum, 32, 64);
+            l_run = l_run * alpha + sum;
+            m_run = m_new;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { om[dt][r] *= alpha; ox[dt][r] *= alpha; }
+            // un-normalised probabilities (<= 1) as the split B operand; the 1 / l normalisation happens once at the end
+            f16x8 ph[NS], pl_[NS];
+#pragma unroll
+            for (int ss = 0; ss < NS; ++ss)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    _Float16 h0, l0, h1 = (_Float16)0.f, l1 = (_Float16)0.f;
+                    split_f32(s[2 * ss][r], h0, l0);
+                    if (2 * ss + 1 < NTB) split_f32(s[(2 * ss + 1 < NTB) ? 2 * ss + 1 : 0][r], h1, l1);
+                    ph[ss][r] = h0; pl_[ss][r] = l0; ph[ss][4 + r] = h1; pl_[ss][4 + r] = l1;
+                }
+#pragma unroll
+            for (int ss = 0; ss < NS; ++ss) {
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    const int vo = (dt * 16 + fr) * VP + (((dt * 16 + fr) >> 3) & 7) * 8 + ss * 32 + g * 4;
+                    const bool two = 2 * ss + 1 < NTB;
+                    const f16x4 a0 = *(const f16x4*)(Vt + vo), a1 = two ? *(const f16x4*)(Vt + vo + 16) : f16x4{0, 0, 0, 0};
+                    const f16x4 b0 = *(const f16x4*)(Vt + D * VP + vo), b1 = two ? *(const f16x4*)(Vt + D * VP + vo + 16) : f16x4{0, 0, 0, 0};
+                    const f16x8 vh = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+                    const f16x8 vl = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+                    ox[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, pl_[ss], ox[dt], 0, 0, 0);
+                    om[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, ph[ss], om[dt], 0, 0, 0);
+                    ox[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl, ph[ss], ox[dt], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (live && qrow < T) {
+            const float inv = 1.f / l_run;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                if (dt * 16 + g * 4 >= dm) continue;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaf(ox[dt][r], SPLIT_LO_INV, om[dt][r]) * inv;
+                store_h_rt<4>(ctx, ((long)b * T + qrow) * H + head * dm + dt * 16 + g * 4, ctx_lo, v);
+            }
+        }
+    }
+}
+
 }  // namespace advh
 
 using namespace advh;
@@ -420,6 +570,8 @@ int advh_init_attention() {
                             (int)att_x3_lds(NT_, D_)) != hipSuccess) return ADVH_ELAUNCH;
     X3A(4, 32) X3A(8, 32) X3A(13, 32) X3A(16, 32) X3A(4, 64) X3A(8, 64) X3A(13, 64) X3A(16, 64)
 #undef X3A
+    if (hipFuncSetAttribute((const void*)attention_x3_stream_kernel<7, 128>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)att_x3_lds(7, 128)) != hipSuccess) return ADVH_ELAUNCH;
     return ADVH_OK;
 }
 
@@ -427,7 +579,12 @@ extern "C" int advh_attention_split(const void* qkv, int64_t qkv_lo, void* ctx, 
                                     advh_stream_t stream) {
     if (!qkv || !ctx || B <= 0 || T <= 0 || heads <= 0 || H % heads || qkv_lo <= 0 || ctx_lo <= 0 || qkv_lo % 8 || ctx_lo % 4) return ADVH_EINVAL;
     const int dm = H / heads;
-    if (T > 256 || dm % 8 || dm > 64) return ADVH_EUNSUPPORTED;
+    if (T > 256 || dm % 8 || dm > 128) return ADVH_EUNSUPPORTED;
+    if (dm > 64) {                                       // keys streamed in blocks of 112 with an online softmax
+        hipLaunchKernelGGL((attention_x3_stream_kernel<7, 128>), dim3(heads, B), dim3(512), att_x3_lds(7, 128), (hipStream_t)stream,
+                           (const _Float16*)qkv, (long)qkv_lo, (_Float16*)ctx, (long)ctx_lo, T, H, dm, 1.f / sqrtf((float)dm));
+        return ADVH_LAUNCH_CHECK();
+    }
     const int D = dm <= 32 ? 32 : 64;
     const float scale = 1.f / sqrtf((float)dm);
     dim3 grid(heads, B);
