@@ -138,3 +138,61 @@ def test_run_addvisor_metrics_ragged_batches_4s(gpu_device, capsys):
         LMAC_metrics.audio_processor.audio_length = 5
         os.environ.pop("ADDVISOR_EMBEDDER", None)
         runtime.reset()
+
+
+def _sharded_metrics_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ["ADDVISOR_EMBEDDER"] = "tiny"
+    dist.init_process_group("gloo", rank=rank, world_size=world)       # one GPU on the test box: the exchange is rehearsed over gloo
+    import LMAC_metrics
+    LMAC_metrics.audio_processor.audio_length = 1
+    clips = syn.make_clips(7, 16000, seed=95)
+    dev = torch.device("cuda:0")
+
+    class DS(torch.utils.data.Dataset):
+        def __len__(self):
+            return 7
+
+        def __getitem__(self, i):
+            return clips[i].to(dev), f"clip{i}.wav"
+
+    m = LMAC_metrics.run_addvisor_metrics("", "", batch_size=2, dataset=DS())
+    q.put((rank, m))
+    dist.destroy_process_group()
+
+
+def test_run_addvisor_metrics_sharded_two_ranks(gpu_device, capsys):
+    """BASELINE config 4's structure through the drop-in module: under torch.distributed run_addvisor_metrics walks each rank's
+    contiguous block (7 clips -> 4 + 3), combines the per-clip probabilities with one all_gather into clip order and reduces
+    them identically everywhere: both ranks return the SAME five numbers, equal to the single-process run bit for bit."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 35500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_sharded_metrics_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = dict(q.get(timeout=600) for _ in procs)
+    [p.join(120) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    assert res[0] == res[1]
+    os.environ["ADDVISOR_EMBEDDER"] = "tiny"
+    runtime.reset()
+    try:
+        import LMAC_metrics
+        LMAC_metrics.audio_processor.audio_length = 1
+        clips = syn.make_clips(7, 16000, seed=95)
+
+        class DS(torch.utils.data.Dataset):
+            def __len__(self):
+                return 7
+
+            def __getitem__(self, i):
+                return clips[i].to(gpu_device), f"clip{i}.wav"
+
+        single = LMAC_metrics.run_addvisor_metrics("", "", batch_size=2, dataset=DS())
+    finally:
+        LMAC_metrics.audio_processor.audio_length = 5
+        os.environ.pop("ADDVISOR_EMBEDDER", None)
+        runtime.reset()
+    assert single == res[0], (single, res[0])

@@ -129,18 +129,36 @@ def explain_batch(waveforms, magnitude, phase, domain="log1p"):
 
 
 def run_addvisor_metrics(dir_path1, dir_path2, batch_size=4, dataset=None):
-    """LMAC_metrics.py:117-172: prints the five means with two decimals."""
-    from torch.utils.data import DataLoader
+    """LMAC_metrics.py:117-172: prints the five means with two decimals.
+
+    Under ``torch.distributed`` (one process per GPU, e.g. ``torchrun --nproc-per-node 8``: BASELINE config 4) every rank walks
+    only its contiguous block of the data set (``pipeline.shard_indices``: utterances are independent, so there is no data-path
+    collective), the per-clip probabilities are combined by ONE all_gather into clip order (``gather_probabilities``: RCCL over
+    xGMI) and every rank reduces the same vector in the same order: the five numbers are bit-identical for any world size;
+    rank 0 prints them."""
+    from torch.utils.data import DataLoader, Subset
+    import torch.distributed as dist
     dataset = dataset or AudioDataset(dir_path1, dir_path2, audio_processor, device)
+    n_total = len(dataset)
+    sharded = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    if sharded:
+        dataset = Subset(dataset, list(_P.shard_indices(n_total, dist.get_rank(), dist.get_world_size())))
     loader = DataLoader(dataset, batch_size=batch_size, shuffle=False, collate_fn=collate_fn)
     theta_out, predictions, masked_predictions = [], [], []
     for waveforms, magnitude, phase, features, filenames in loader:
         with torch.no_grad():
             p, t, o = explain_batch(waveforms, magnitude, phase)
             predictions.append(p), theta_out.append(t), masked_predictions.append(o)
-    predictions, theta_out = torch.cat(predictions, 0), torch.cat(theta_out, 0)
-    masked_predictions = torch.cat(masked_predictions, 0)
+    if predictions:
+        local = torch.cat([torch.cat(predictions, 0), torch.cat(theta_out, 0), torch.cat(masked_predictions, 0)], 1)
+    else:                                                   # a rank whose block is empty (more ranks than clips)
+        local = torch.zeros((0, 3), dtype=torch.float32, device=device)
+    if sharded:
+        local = _P.gather_probabilities(local.contiguous(), n_total)
+    predictions, theta_out, masked_predictions = (local[:, i:i + 1].contiguous() for i in range(3))
     m = _P.lmac_metrics(predictions, theta_out, masked_predictions)
+    if sharded and dist.get_rank() != 0:
+        return m
     print(f"faithfulness : {m['faithfulness']:.2f}")
     print(f"fidelity: {m['fidelity']:.2f}")
     print(f"average drop : {m['AD']:.2f}")

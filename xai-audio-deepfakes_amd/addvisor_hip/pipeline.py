@@ -174,8 +174,11 @@ def gather_probabilities(local: torch.Tensor, n_total: int, group=None) -> torch
         return local
     world = dist.get_world_size(group)
     per = -(-n_total // world)
+    dev = local.device
+    if local.is_cuda and dist.get_backend(group) == "gloo":      # gloo has no GPU all_gather (one-GPU rehearsals): stage through the host
+        local = local.cpu()
     pad = torch.zeros((per, 3), dtype=local.dtype, device=local.device)
     pad[: local.shape[0]] = local
     parts = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(parts, pad, group=group)
-    return torch.cat(parts, 0)[:n_total]
+    return torch.cat(parts, 0)[:n_total].to(dev)
