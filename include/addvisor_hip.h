@@ -381,6 +381,14 @@ int advh_unet_pack_x_split(const float* mag, int Fq, int Tq, int B, int H, int W
                            int PH, int PW, advh_stream_t stream);
 int advh_unet_head_split(const void* y, int64_t y_lo, int B, int H, int W, int PH, int PW, const float* wgt, float bias,
                          float* mask, float* logits, advh_stream_t stream);
+/* HiFi-GAN generator pieces on split-format maps [2][B][T+2*halo][C] (the Conv1d / ConvTranspose1d layers are advh_gemm_f16
+ * launches with desc.split = 1; advh_halo_fill_f16 serves both planes when called with 2*B maps).  `pad` = inference padding. */
+int advh_hifigan_pack_mel_split(const float* mel, void* out, int64_t out_lo, int B, int C, int T, int pad, int halo,
+                                advh_stream_t stream);
+int advh_hifigan_mrf_mix_split(const void* a, const void* b, const void* c, void* y, float slope, int64_t numel, int64_t lo,
+                               advh_stream_t stream);
+int advh_hifigan_conv_post_split(const void* x, int64_t x_lo, const float* w, float bias, float* wav, int B, int C, int T, int halo,
+                                 int k, advh_stream_t stream);
 
 /* ---- LDS line-tile convolution for narrow layers (C_in = C_out = C in {32, 64}) -------------------------------
  * out[m][co] = act(bias[co] + sum_t sum_ci W[t][co][ci] * X[m + toff[t]][ci]) (+ resid[m][co]) over the M rows of a

@@ -72,3 +72,21 @@ def test_speechbrain_wrapper_options(gpu_device, padding_mode, inference_padding
     assert err.max().item() <= TOL_MAX and err.mean().item() <= TOL_MEAN
     again = net.decode_batch(mel.to(gpu_device))                          # halos are refilled on every call
     assert torch.equal(again, wav)
+
+
+@pytest.mark.parametrize("padding_mode,inference_padding", [("zeros", 0), ("reflect", 5)])
+def test_v1_generator_f32_mode(gpu_device, padding_mode, inference_padding):
+    """The fp32-class mode of the explanation path (split-format maps, three MFMAs per product) on the vocoder: ~50 stacked
+    convolutions to 2e-5 of the oracle (fp32 CPU; stated tolerance 1e-4 on a waveform in [-1, 1]) where the fp16 mode gives 1.4e-3."""
+    cfg = syn.HifiganConfig()
+    sd = syn.hifigan_weights(cfg)
+    r = np.random.Generator(np.random.PCG64(6))
+    mel = torch.from_numpy(r.normal(-4.0, 2.0, size=(2, cfg.in_channels, 24)).astype(np.float32))
+    net = HipHifigan(cfg, sd, gpu_device, padding_mode=padding_mode, inference_padding=inference_padding, precision="f32")
+    wav = net.decode_batch(mel.to(gpu_device))
+    ref = hifigan_ref.generator(mel, sd, cfg, padding_mode=padding_mode, inference_padding=inference_padding)
+    assert wav.shape == ref.shape
+    err = (wav.cpu() - ref).abs()
+    print(f"hifigan f32 mode ({padding_mode}, pad {inference_padding}): max err {err.max():.3e} mean {err.mean():.3e}")
+    assert err.max().item() <= 1e-4 and err.mean().item() <= 1e-5
+    assert torch.equal(net.decode_batch(mel[:1].to(gpu_device))[0], wav[0])     # batch invariance

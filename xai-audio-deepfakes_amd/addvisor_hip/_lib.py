@@ -99,6 +99,9 @@ SIGNATURES = {
     "advh_attention_split": (_i, [_p, _i64, _p, _i64, _i, _i, _i, _i, _p]),
     "advh_unet_stem_split": (_i, [_p, _i, _i, _i, _i, _i, _p, _p, _p, _i64, _i, _i, _f, _p]),
     "advh_unet_pack_x_split": (_i, [_p, _i, _i, _i, _i, _i, _p, _i64, _i, _i, _i, _i, _p]),
+    "advh_hifigan_pack_mel_split": (_i, [_p, _p, _i64, _i, _i, _i, _i, _i, _p]),
+    "advh_hifigan_mrf_mix_split": (_i, [_p, _p, _p, _p, _f, _i64, _i64, _p]),
+    "advh_hifigan_conv_post_split": (_i, [_p, _i64, _p, _f, _p, _i, _i, _i, _i, _i, _p]),
     "advh_unet_head_split": (_i, [_p, _i64, _i, _i, _i, _i, _i, _p, _f, _p, _p, _p]),
     "advh_upconv21_tile_lds_bytes": (_i, []),
 }

@@ -330,6 +330,16 @@ class GemmPlan:
         d.A0 = A0.data_ptr()
         d.A1 = A1.data_ptr() if A1 is not None else None
         assert (A1 is not None) == (self.nsrc == 2)
+        if d.plain:
+            # affine-row loader: row m reads Ktot contiguous halfs at chunk a_c0 + m * a_sW for EVERY m < M (filler rows too):
+            # the furthest byte must lie inside the operand (its plane, in split mode) -- the slack rows behind the
+            # feature-encoder buffers exist for this; a mismatch between the allocation and the plan must fail here, on
+            # the host, not as an out-of-bounds DMA on the device
+            plane = A0.stride(0) if self.split else A0.numel()
+            need = (int(d.a_c0[0]) + (d.M - 1) * int(d.a_sW[0])) * 8 + d.Ktot + int(d.a_sZ[0]) * 8 * max(0, d.nz - 1)
+            if need > plane:
+                raise ValueError(f"affine-row GEMM operand too small: the plan reads {need} halfs per plane, the tensor holds {plane} "
+                                 "(missing slack rows behind the buffer?)")
         d.W, d.ktab = self.w.data_ptr(), self.ktab.data_ptr()
         d.bias = self.bias.data_ptr() if self.bias is not None else None
         d.out_h = out_h.data_ptr() if out_h is not None else None
@@ -774,17 +784,20 @@ class Map1D:
     C: int
     halo: int
     t: Optional[torch.Tensor] = None
+    split: bool = False          # fp32-class mode: ``t`` is the plane pair [2, B, P, C]
 
     @property
     def P(self):
         return self.T + 2 * self.halo
 
     def alloc(self, device):
-        self.t = torch.zeros((self.B, self.P, self.C), dtype=torch.float16, device=device)
+        shape = (self.B, self.P, self.C)
+        self.t = torch.zeros(((2,) + shape) if self.split else shape, dtype=torch.float16, device=device)
         return self
 
     def interior(self) -> torch.Tensor:
-        return self.t[:, self.halo:self.halo + self.T]
+        t = self.t[0] if self.split else self.t
+        return t[:, self.halo:self.halo + self.T]
 
 
 def plan_conv1d_same(src: Map1D, dst: Map1D, weight: torch.Tensor, bias: Optional[torch.Tensor], *, dilation: int = 1,
@@ -797,10 +810,11 @@ def plan_conv1d_same(src: Map1D, dst: Map1D, weight: torch.Tensor, bias: Optiona
     cc = Cin // 8
     kt = (np.arange(k)[:, None] * dilation * cc + np.arange(cc)[None, :]).reshape(-1).astype(np.int64)
     w2 = weight.permute(0, 2, 1).reshape(1, Cout, k * Cin).float()
+    assert src.split == dst.split
     return GemmPlan(M=dst.B * dst.P, N=Cout, w2=w2, ktab=kt,
                     sources=[Source(src.P * cc, 0, cc, (src.halo - dst.halo - pad) * cc)], Hg=1, Wg=dst.P,
                     window=(0, 1, dst.halo, dst.halo + dst.T), halo_zero=True, out=(dst.P * dst.C, 0, dst.C, 0),
-                    bias=bias, act=act, slope=slope, slope2=slope2, device=device)
+                    bias=bias, act=act, slope=slope, slope2=slope2, device=device, split=dst.split)
 
 
 
@@ -1040,4 +1054,4 @@ def plan_convT1d(src: Map1D, dst: Map1D, weight: torch.Tensor, bias: torch.Tenso
                     sources=[Source(src.P * cc, 0, cc, (src.halo - 1) * cc)], Hg=1, Wg=src.T + 1,
                     window=(0, 1, 0, src.T + 1), halo_zero=False,
                     out=(dst.P * dst.C, 0, r * dst.C, (dst.halo - pad) * dst.C), n_div=Cout, o_sNhi=dst.C,
-                    bias=bias.float().repeat(r), slope2=slope2, phase=(r, pad, dst.T), device=device)
+                    bias=bias.float().repeat(r), slope2=slope2, phase=(r, pad, dst.T), device=device, split=dst.split)

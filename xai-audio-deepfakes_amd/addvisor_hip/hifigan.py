@@ -28,12 +28,18 @@ HALO = 32          # >= the largest "same" padding: (11 - 1) * 5 / 2 = 25
 
 class HipHifigan:
     def __init__(self, cfg: HifiganConfig, sd: Dict[str, torch.Tensor], device, line_tile: bool = True, fuse: bool = True,
-                 padding_mode: str = "zeros", inference_padding: int = 0):
+                 padding_mode: str = "zeros", inference_padding: int = 0, precision: str = "f16"):
         """``line_tile``: run the 32- / 64-channel ResBlock convolutions on the weights-in-LDS kernel
         (``advh_conv_taps_f16``) instead of the implicit GEMM; ``fuse``: whole ResBlock steps in one kernel where both
         weight tensors fit in LDS (``advh_resblock_pair_f16``).  ``padding_mode`` / ``inference_padding``: see the module
-        docstring."""
+        docstring.  ``precision``: "f16" (default: the vocoder's stated tolerance is on waveforms) or "f32" -- the
+        fp32-class mode of the explanation path (split-format maps, three MFMAs per product; implicit GEMM only)."""
         _lib.init()
+        if precision not in ("f16", "f32"):
+            raise ValueError("precision must be 'f16' or 'f32'")
+        self.precision, self.split = precision, precision == "f32"
+        if self.split:
+            line_tile = fuse = False                       # the line-tile kernels are fp16-only
         if padding_mode not in ("zeros", "reflect"):
             raise ValueError("padding_mode must be 'zeros' or 'reflect'")
         if inference_padding < 0:
@@ -59,7 +65,7 @@ class HipHifigan:
         if key in self._ws:
             return self._ws[key]
         cfg, sd, dev = self.cfg, self.sd, self.dev
-        M = lambda t, c: G.Map1D(B, t, c, HALO).alloc(dev)
+        M = lambda t, c: G.Map1D(B, t, c, HALO, split=self.split).alloc(dev)
 
         def conv(src, dst, w, b, **kw):
             if self.line_tile and G.taps_supported(src, dst, w, kw.get("dilation", 1)):
@@ -151,20 +157,33 @@ class HipHifigan:
         T = T0 + 2 * pad
         ws = self._workspace(B, T)
         lib, st = _lib.lib(), torch.cuda.current_stream().cuda_stream
-        if pad:
+        sp = self.split
+        if sp:
+            _lib.check(lib.advh_hifigan_pack_mel_split(mel.data_ptr(), ws["mel"].t.data_ptr(), ws["mel"].t.stride(0), B, C, T0, pad, HALO, st),
+                       "advh_hifigan_pack_mel_split")
+        elif pad:
             _lib.check(lib.advh_hifigan_pack_mel_pad(mel.data_ptr(), ws["mel"].t.data_ptr(), B, C, T0, pad, HALO, st), "advh_hifigan_pack_mel_pad")
         else:
             _lib.check(lib.advh_hifigan_pack_mel(mel.data_ptr(), ws["mel"].t.data_ptr(), B, C, T, HALO, st), "advh_hifigan_pack_mel")
         for kind, plan, src, resid, dst, dst2 in ws["steps"]:
             if kind == "gemm":
                 plan.run(src.t, out_h=dst.t, resid=None if resid is None else resid.t, out_h2=None if dst2 is None else dst2.t)
-            elif kind == "halo":
-                _lib.check(lib.advh_halo_fill_f16(src.t.data_ptr(), src.B, src.T, src.C, src.halo, plan, st), "advh_halo_fill_f16")
+            elif kind == "halo":                       # split maps: both planes are [B][P][C] images of the same geometry
+                _lib.check(lib.advh_halo_fill_f16(src.t.data_ptr(), src.B * (2 if sp else 1), src.T, src.C, src.halo, plan, st), "advh_halo_fill_f16")
+            elif sp:
+                a, b, c = src
+                _lib.check(lib.advh_hifigan_mrf_mix_split(a.t.data_ptr(), b.t.data_ptr(), c.t.data_ptr(), dst.t.data_ptr(), plan,
+                                                          dst.t.stride(0), dst.t.stride(0), st), "advh_hifigan_mrf_mix_split")
             else:
                 a, b, c = src
                 _lib.check(lib.advh_hifigan_mrf_mix(a.t.data_ptr(), b.t.data_ptr(), c.t.data_ptr(), dst.t.data_ptr(), plan,
                                                     dst.t.numel(), st), "advh_hifigan_mrf_mix")
         last = ws["last"]
-        _lib.check(lib.advh_hifigan_conv_post(last.t.data_ptr(), self.post_w.data_ptr(), self.post_b, ws["wav"].data_ptr(), B,
-                                              last.C, last.T, HALO, self.cfg.post_kernel, st), "advh_hifigan_conv_post")
+        if sp:
+            _lib.check(lib.advh_hifigan_conv_post_split(last.t.data_ptr(), last.t.stride(0), self.post_w.data_ptr(), self.post_b,
+                                                        ws["wav"].data_ptr(), B, last.C, last.T, HALO, self.cfg.post_kernel, st),
+                       "advh_hifigan_conv_post_split")
+        else:
+            _lib.check(lib.advh_hifigan_conv_post(last.t.data_ptr(), self.post_w.data_ptr(), self.post_b, ws["wav"].data_ptr(), B,
+                                                  last.C, last.T, HALO, self.cfg.post_kernel, st), "advh_hifigan_conv_post")
         return ws["wav"].clone()

@@ -5,6 +5,7 @@
 #include <hip/hip_fp16.h>
 #include "addvisor_hip.h"
 #include "common.h"
+#include "device_math.h"
 
 namespace advh {
 
@@ -12,19 +13,20 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 // mel [B][C][T] fp32 (torch layout) -> zero-haloed channels-last fp16 [B][T+2*halo][C]   (interior only)
 __global__ __launch_bounds__(256) void pack_mel_kernel(const float* __restrict__ mel, _Float16* __restrict__ out,
-                                                       int C, int T, int halo, long total) {
+                                                       int C, int T, int halo, long total, long out_lo) {
     long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
     int c = (int)(i % C);
     long r = i / C;
     int t = (int)(r % T), b = (int)(r / T);
-    out[((long)b * (T + 2 * halo) + t + halo) * C + c] = (_Float16)mel[((long)b * C + c) * T + t];
+    const float v[1] = {mel[((long)b * C + c) * T + t]};
+    store_h_rt<1>(out, ((long)b * (T + 2 * halo) + t + halo) * C + c, out_lo, v);
 }
 
 // Same with `pad` replicated frames in front and behind (SpeechBrain / Coqui `inference_padding`: F.pad(mel, (p, p),
 // "replicate") before the generator); the map holds T + 2 pad interior rows.
 __global__ __launch_bounds__(256) void pack_mel_pad_kernel(const float* __restrict__ mel, _Float16* __restrict__ out,
-                                                           int C, int T, int pad, int halo, long total) {
+                                                           int C, int T, int pad, int halo, long total, long out_lo) {
     long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
     const int Tp = T + 2 * pad;
@@ -32,7 +34,8 @@ __global__ __launch_bounds__(256) void pack_mel_pad_kernel(const float* __restri
     long r = i / C;
     int t = (int)(r % Tp), b = (int)(r / Tp);
     int ts = min(max(t - pad, 0), T - 1);
-    out[((long)b * (Tp + 2 * halo) + t + halo) * C + c] = (_Float16)mel[((long)b * C + c) * T + ts];
+    const float v[1] = {mel[((long)b * C + c) * T + ts]};
+    store_h_rt<1>(out, ((long)b * (Tp + 2 * halo) + t + halo) * C + c, out_lo, v);
 }
 
 // Halo fill of a channels-last map [B][T + 2 halo][C]: mode 0 = zeros, mode 1 = reflection about the first / last
@@ -56,31 +59,37 @@ __global__ __launch_bounds__(256) void halo_fill_kernel(_Float16* __restrict__ x
 }
 
 // MRF mix: y = LeakyReLU_slope((a + b + c) / 3), whole padded maps (zero halo stays zero)
-__global__ __launch_bounds__(256) void mrf_mix_kernel(const f16x8* __restrict__ a, const f16x8* __restrict__ b,
-                                                      const f16x8* __restrict__ c, f16x8* __restrict__ y, float slope, long n8) {
+__global__ __launch_bounds__(256) void mrf_mix_kernel(const _Float16* __restrict__ a, const _Float16* __restrict__ b,
+                                                      const _Float16* __restrict__ c, _Float16* __restrict__ y, float slope, long n8,
+                                                      long lo) {     // lo != 0: split-format maps (plane pairs, lo plane `lo` elements behind)
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
-        f16x8 va = a[i], vb = b[i], vc = c[i], o;
+        float va[8], vb[8], vc[8], o[8];
+        load_h_rt<8>(a, i * 8, lo, va);
+        load_h_rt<8>(b, i * 8, lo, vb);
+        load_h_rt<8>(c, i * 8, lo, vc);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            float v = ((float)va[j] + (float)vb[j] + (float)vc[j]) * (1.f / 3.f);
-            o[j] = (_Float16)(v > 0.f ? v : slope * v);
+            const float v = (va[j] + vb[j] + vc[j]) * (1.f / 3.f);
+            o[j] = v > 0.f ? v : slope * v;
         }
-        y[i] = o;
+        store_h_rt<8>(y, i * 8, lo, o);
     }
 }
 
 // conv_post: Conv1d(C -> 1, k, "same") + tanh on a pre-activated zero-haloed map; wav [B][1][T] fp32
 __global__ __launch_bounds__(256) void conv_post_kernel(const _Float16* __restrict__ x, const float* __restrict__ w /*[k][C]*/,
-                                                        float bias, float* __restrict__ wav, int C, int T, int halo, int k, long total) {
+                                                        float bias, float* __restrict__ wav, int C, int T, int halo, int k, long total,
+                                                        long x_lo) {
     long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
     int t = (int)(i % T), b = (int)(i / T);
-    const _Float16* p = x + ((long)b * (T + 2 * halo) + t + halo - (k - 1) / 2) * C;
+    const long p = ((long)b * (T + 2 * halo) + t + halo - (k - 1) / 2) * C;
     float acc = bias;
     for (int j = 0; j < k * C; j += 8) {
-        f16x8 v = *(const f16x8*)(p + j);
+        float v[8];
+        load_h_rt<8>(x, p + j, x_lo, v);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc = fmaf((float)v[e], w[j + e], acc);
+        for (int e = 0; e < 8; ++e) acc = fmaf(v[e], w[j + e], acc);
     }
     wav[i] = tanhf(acc);
 }
@@ -103,18 +112,32 @@ __global__ __launch_bounds__(256) void mel_log_kernel(const float* __restrict__ 
 
 using namespace advh;
 
-extern "C" int advh_hifigan_pack_mel(const float* mel, void* out, int B, int C, int T, int halo, advh_stream_t stream) {
-    if (!mel || !out || B <= 0 || C <= 0 || T <= 0 || halo < 0) return ADVH_EINVAL;
-    long total = (long)B * C * T;
-    hipLaunchKernelGGL(pack_mel_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, mel, (_Float16*)out, C, T, halo, total);
+static int pack_mel_launch(const float* mel, void* out, int64_t out_lo, int B, int C, int T, int pad, int halo, advh_stream_t stream) {
+    if (!mel || !out || B <= 0 || C <= 0 || T <= 0 || halo < 0 || pad < 0 || out_lo < 0) return ADVH_EINVAL;
+    if (pad == 0) {
+        long total = (long)B * C * T;
+        hipLaunchKernelGGL(pack_mel_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, mel, (_Float16*)out, C, T, halo, total,
+                           (long)out_lo);
+    } else {
+        long total = (long)B * C * (T + 2 * pad);
+        hipLaunchKernelGGL(pack_mel_pad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, mel, (_Float16*)out, C, T, pad,
+                           halo, total, (long)out_lo);
+    }
     return ADVH_LAUNCH_CHECK();
 }
 
+extern "C" int advh_hifigan_pack_mel(const float* mel, void* out, int B, int C, int T, int halo, advh_stream_t stream) {
+    return pack_mel_launch(mel, out, 0, B, C, T, 0, halo, stream);
+}
+
+extern "C" int advh_hifigan_pack_mel_split(const float* mel, void* out, int64_t out_lo, int B, int C, int T, int pad, int halo,
+                                           advh_stream_t stream) {
+    if (out_lo <= 0) return ADVH_EINVAL;
+    return pack_mel_launch(mel, out, out_lo, B, C, T, pad, halo, stream);
+}
+
 extern "C" int advh_hifigan_pack_mel_pad(const float* mel, void* out, int B, int C, int T, int pad, int halo, advh_stream_t stream) {
-    if (!mel || !out || B <= 0 || C <= 0 || T <= 0 || halo < 0 || pad < 0) return ADVH_EINVAL;
-    long total = (long)B * C * (T + 2 * pad);
-    hipLaunchKernelGGL(pack_mel_pad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, mel, (_Float16*)out, C, T, pad, halo, total);
-    return ADVH_LAUNCH_CHECK();
+    return pack_mel_launch(mel, out, 0, B, C, T, pad, halo, stream);
 }
 
 extern "C" int advh_halo_fill_f16(void* x, int B, int T, int C, int halo, int mode, advh_stream_t stream) {
@@ -125,23 +148,44 @@ extern "C" int advh_halo_fill_f16(void* x, int B, int T, int C, int halo, int mo
     return ADVH_LAUNCH_CHECK();
 }
 
-extern "C" int advh_hifigan_mrf_mix(const void* a, const void* b, const void* c, void* y, float slope, int64_t numel, advh_stream_t stream) {
-    if (!a || !b || !c || !y || numel <= 0 || numel % 8) return ADVH_EINVAL;
+static int mrf_mix_launch(const void* a, const void* b, const void* c, void* y, float slope, int64_t numel, int64_t lo, advh_stream_t stream) {
+    if (!a || !b || !c || !y || numel <= 0 || numel % 8 || lo < 0 || lo % 8) return ADVH_EINVAL;
     long n8 = numel / 8;
     long blocks = (n8 + 255) / 256;
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(mrf_mix_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const f16x8*)a, (const f16x8*)b,
-                       (const f16x8*)c, (f16x8*)y, slope, n8);
+    hipLaunchKernelGGL(mrf_mix_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const _Float16*)a, (const _Float16*)b,
+                       (const _Float16*)c, (_Float16*)y, slope, n8, (long)lo);
+    return ADVH_LAUNCH_CHECK();
+}
+
+extern "C" int advh_hifigan_mrf_mix(const void* a, const void* b, const void* c, void* y, float slope, int64_t numel, advh_stream_t stream) {
+    return mrf_mix_launch(a, b, c, y, slope, numel, 0, stream);
+}
+
+extern "C" int advh_hifigan_mrf_mix_split(const void* a, const void* b, const void* c, void* y, float slope, int64_t numel, int64_t lo,
+                                          advh_stream_t stream) {
+    if (lo <= 0) return ADVH_EINVAL;
+    return mrf_mix_launch(a, b, c, y, slope, numel, lo, stream);
+}
+
+static int conv_post_launch(const void* x, int64_t x_lo, const float* w, float bias, float* wav, int B, int C, int T, int halo, int k,
+                            advh_stream_t stream) {
+    if (!x || !w || !wav || B <= 0 || C <= 0 || C % 8 || T <= 0 || k <= 0 || !(k & 1) || halo < (k - 1) / 2 || x_lo < 0) return ADVH_EINVAL;
+    long total = (long)B * T;
+    hipLaunchKernelGGL(conv_post_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const _Float16*)x, w,
+                       bias, wav, C, T, halo, k, total, (long)x_lo);
     return ADVH_LAUNCH_CHECK();
 }
 
 extern "C" int advh_hifigan_conv_post(const void* x, const float* w, float bias, float* wav, int B, int C, int T, int halo, int k,
                                       advh_stream_t stream) {
-    if (!x || !w || !wav || B <= 0 || C <= 0 || C % 8 || T <= 0 || k <= 0 || !(k & 1) || halo < (k - 1) / 2) return ADVH_EINVAL;
-    long total = (long)B * T;
-    hipLaunchKernelGGL(conv_post_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const _Float16*)x, w,
-                       bias, wav, C, T, halo, k, total);
-    return ADVH_LAUNCH_CHECK();
+    return conv_post_launch(x, 0, w, bias, wav, B, C, T, halo, k, stream);
+}
+
+extern "C" int advh_hifigan_conv_post_split(const void* x, int64_t x_lo, const float* w, float bias, float* wav, int B, int C, int T, int halo,
+                                            int k, advh_stream_t stream) {
+    if (x_lo <= 0) return ADVH_EINVAL;
+    return conv_post_launch(x, x_lo, w, bias, wav, B, C, T, halo, k, stream);
 }
 
 extern "C" int advh_mel_log(const float* mag, const float* fb, float* out, int B, int F, int T, int n_mels, advh_stream_t stream) {
