@@ -116,7 +116,7 @@ __device__ __forceinline__ float mask_factor(float m, float M, int mode) {
 struct AdjArgs { const float* mask; float* dmask; int Fm, Tm, mode, which; };
 
 template <int FB, int ADJ>
-__global__ __launch_bounds__(THREADS, 4) void stft_fwd_kernel(
+__global__ __launch_bounds__(THREADS, 6) void stft_fwd_kernel(
     const float* __restrict__ wave, long wave_stride, int n_in, int L, int hop, int win,
     const float* __restrict__ window, float* __restrict__ X, float* __restrict__ mag,
     float* __restrict__ phase, int T, AdjArgs adj) {
@@ -267,13 +267,12 @@ __global__ __launch_bounds__(THREADS, 4) void stft_fwd_kernel(
 // ------------------------------------------------------------------------------------------ inverse
 // SRC 3: complex64 spectrogram X (in `mag`) + mask: X' = X * g(m, |X|) / |X| -- the mask application of SRC 0 without the
 // polar round trip (no atan2 in the forward, no sincos here); what the explanation pipeline runs.
-// SRC 0 / 3 with both outputs requested: ONE workgroup produces mask-in and mask-out in two passes over the same tile
-// (the second pass re-reads it from L2), so the spectrogram leaves HBM once per explanation, not once per resynthesis.
+// SRC 0 / 3 with both outputs requested: grid z = 2, one workgroup per branch (the second branch's tile reads hit L2).
 // SRC 0: mag/phase (+ optional mask, mode), SRC 1: complex64 spectrogram, SRC 2: band swap of two complex64
 // spectrograms (hifigan.py:208-222, train_logReg_swapping.py:70-81): grid z = band, bins [Fm + z*Tm, Fm + (z+1)*Tm)
 // come from `phase` (the vocoded signal), all others from `mag` (the original); output z at out0 + z * out1_stride.
 template <int SRC, int FB>
-__global__ __launch_bounds__(THREADS, 2) void istft_kernel(
+__global__ __launch_bounds__(THREADS, 4) void istft_kernel(
     const float* __restrict__ mag, const float* __restrict__ phase, const float* __restrict__ mask,
     int Fm, int Tm, int mode, int which0, float* __restrict__ out0, float* __restrict__ out1,
     long wave_stride, int T, int L, int hop, int win, int R, const float* __restrict__ window, long zstride) {
@@ -287,9 +286,10 @@ __global__ __launch_bounds__(THREADS, 2) void istft_kernel(
     const int S = FB - R + 1;                         // complete hop-segments this workgroup emits
     const int tA = g * S - (R - 1);                   // first frame it transforms (may be < 0)
     const int nacc = (FB - 1) * hop + win;
-    const int npass = (SRC == 0 || SRC == 3) ? (out1 ? 2 : 1) : 1;
-    LaneTw ltw;
-    load_lane_twiddles(lane, ltw);
+    // mask-in / mask-out are two workgroups (grid z): round 2 first ran them as two passes of one workgroup over tile values
+    // kept in registers (one HBM read of the spectrogram), but the 27 live tile registers pushed the kernel to 191 VGPRs = ONE
+    // workgroup per CU; as separate workgroups (the second read comes from L2) it fits 128 VGPRs = two per CU and is faster.
+    const int pass = blockIdx.z;
     // tile loads: element idx = tid + it * THREADS -> (frame tl = idx % FB, bin k = idx / FB); SRC 0: (|X|, angle X),
     // SRC 1 / 2 / 3: complex X; ldm = the mask value (0 outside the Fm x Tm crop: SURVEY.md D2/D3)
     constexpr int NIT = (NBIN * FB + THREADS - 1) / THREADS;
@@ -313,10 +313,8 @@ __global__ __launch_bounds__(THREADS, 2) void istft_kernel(
             if ((SRC == 0 || SRC == 3) && mode != ADVH_MASK_NONE && k < Fm && t < Tm) ldm[it] = mask[((long)b * Fm + k) * Tm + t];
         }
     }
-    for (int pass = 0; pass < npass; ++pass) {
-    const int which = which0 + pass;                  // 0: mask-in, 1: mask-out
+    const int which = which0 + (SRC == 2 ? 0 : pass);  // 0: mask-in, 1: mask-out
     float* out = (SRC == 2 ? out0 + (long)blockIdx.z * zstride : (pass == 0 ? out0 : out1)) + (long)b * wave_stride;
-    if (pass) __syncthreads();                        // the accumulator of the previous pass has been emitted
     if (pass == 0) STAMP(4);
 
     // 1. the 513 x FB tile: mask application, polar -> cartesian, into the LDS rows.  The global loads were issued before
@@ -350,6 +348,8 @@ __global__ __launch_bounds__(THREADS, 2) void istft_kernel(
     for (int i = tid; i < nacc; i += THREADS) acc[i] = 0.f;
     __syncthreads();
     if (pass == 0) STAMP(5);
+    LaneTw ltw;                                       // fetched after the tile registers have died
+    load_lane_twiddles(lane, ltw);
 
     // 2. one wavefront per frame: Hermitian glue, inverse FFT512, windowed overlap-add into LDS
     for (int f = wv; f < FB; f += THREADS / 64) {
@@ -409,7 +409,6 @@ __global__ __launch_bounds__(THREADS, 2) void istft_kernel(
         out[n] = env > 1e-11f ? acc[a] / env : 0.f;
     }
     if (pass == 0) STAMP(7);
-    }   // pass
 }
 
 static size_t lds_bytes(int FB, int hop, int win) {
@@ -530,7 +529,7 @@ static int launch_istft(int src, const float* a, const float* ph, const float* m
     else if (!o1) { nz = 1; }
     if (src == 1) p1 = nullptr;
     if (src == 2) nz = nbands;
-    else { if (nz == 1) p1 = nullptr; nz = 1; }      // mask-in and mask-out are two passes of one workgroup (p1 != NULL)
+    else if (nz == 1) p1 = nullptr;
     const int nG = (NFFT / 2 + L - left + S * hop - 1) / (S * hop);
     dim3 grid(nG, B, nz);
 #define ISTFT_LAUNCH(SRC_, FB_)                                                                                          \
