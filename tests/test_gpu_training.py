@@ -203,3 +203,23 @@ def test_train_addvisor_module_end_to_end(gpu_device, tiny_runtime, tmp_path):
     with torch.no_grad():
         x = T.crop_for_model(mag)
         assert torch.equal(net(x), fresh(x))
+
+
+def test_stale_training_forward_is_refused(gpu_device):
+    """The HIP training engine keeps ONE set of saved activations per module: backward of a forward that a later training
+    forward has overwritten must raise instead of silently using the newer activations (round-1 advisor finding)."""
+    import addvisor
+    torch.manual_seed(0)
+    with torch.enable_grad():
+        net = addvisor.UNet().to(gpu_device)
+        net.train()
+        x = torch.rand(2, 1, 32, 8, device=gpu_device)
+        first = net(x)
+        second = net(x * 0.5)
+        with pytest.raises(RuntimeError, match="saved activations were overwritten"):
+            first.sum().backward()
+        second.sum().backward()                                   # the latest forward is still valid
+    assert any(p.grad is not None and torch.isfinite(p.grad).all() and p.grad.abs().sum() > 0 for p in net.parameters())
+    with torch.enable_grad():
+        with pytest.raises(RuntimeError, match="no CPU"):
+            addvisor.UNet().train()(torch.rand(1, 1, 32, 8))      # parameters on the CPU: no eager-torch path any more
