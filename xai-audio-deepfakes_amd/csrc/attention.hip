@@ -532,6 +532,130 @@ __global__ __launch_bounds__(512, 1) void attention_x3_stream_kernel(const _Floa
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// fp32-class attention, head dim 64 (wav2vec2-base / -large): the split-format counterpart of attention_tr_kernel.  K and V
+// of both planes are staged ROW-major by the LDS DMA (no register round trip, no scalar transposing stores, no V^T buffer:
+// attention_x3_kernel spent 35 % of its LDS cycles on bank conflicts of exactly those) and the V^T operand of O^T = V^T P^T is
+// read with ds_read_b64_tr_b16 from either plane.  106 KB of LDS at T = 199; eight wavefronts.
+template <int NT>
+__global__ __launch_bounds__(512, 1) void attention_x3_tr_kernel(const _Float16* __restrict__ qkv, long qkv_lo, _Float16* __restrict__ ctx,
+                                                                 long ctx_lo, int T, int H, float scale) {
+    constexpr int D = 64, NKEY = NT * 16, CH = 8, NS = (NT + 1) / 2, KK = 2, DT = 4;
+    constexpr int PLB = NKEY * D * 2;            // bytes of one plane of K (or V)
+    extern __shared__ __attribute__((aligned(16))) _Float16 att_lds[];
+    char* Ks = (char*)att_lds;                   // [2 planes][NKEY][64] fp16, chunk c of key r at slot c ^ (r & 7)
+    char* Vs = Ks + 2 * PLB;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int head = blockIdx.x, b = blockIdx.y;
+    const long ld = 3L * H;
+    const _Float16* base = qkv + (long)b * T * ld + head * D;
+    for (int i = tid; i < NKEY * CH; i += 512) {          // keys >= T re-read key T-1 (finite; masked by the softmax / multiplied by P = 0)
+        const int key = i / CH, c = (i % CH) ^ (key & 7);
+        const _Float16* src = base + (long)min(key, T - 1) * ld + c * 8;
+        const size_t dst = (size_t)(i - lane) * 16;
+        __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src + H), LDS_PTR(Ks + dst), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src + qkv_lo + H), LDS_PTR(Ks + PLB + dst), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src + 2 * H), LDS_PTR(Vs + dst), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src + qkv_lo + 2 * H), LDS_PTR(Vs + PLB + dst), 16, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int fr = lane & 15, g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    const auto* vs3 = (const __attribute__((address_space(3))) char*)LDS_PTR(Vs);
+    for (int qt = wv; qt * 16 < T; qt += 8) {
+        const int qrow = qt * 16 + fr;
+        const int qr = qrow < T ? qrow : T - 1;
+        f16x8 qh[KK], ql[KK];
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+            qh[kk] = *(const f16x8*)(base + (long)qr * ld + kk * 32 + g * 8);
+            ql[kk] = *(const f16x8*)(base + qkv_lo + (long)qr * ld + kk * 32 + g * 8);
+        }
+        f32x4 s[NT];
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+            f32x4 sm = f32x4{0.f, 0.f, 0.f, 0.f}, sx = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) {
+                const int key = kt * 16 + fr, c = kk * 4 + g;
+                const int o = (key * CH + (c ^ (key & 7))) * 16;
+                const f16x8 kh = *(const f16x8*)(Ks + o), kl = *(const f16x8*)(Ks + PLB + o);
+                sx = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, ql[kk], sx, 0, 0, 0);
+                sm = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, qh[kk], sm, 0, 0, 0);
+                sx = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl, qh[kk], sx, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[kt][r] = fmaf(sx[r], SPLIT_LO_INV, sm[r]);
+            if ((kt & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = (kt * 16 + g * 4 + r < T) ? s[kt][r] * (scale * LOG2E) : -INFINITY;
+                s[kt][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const float e = exp2f(s[kt][r] - mx); s[kt][r] = e; sum += e; }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.f / sum;
+        f16x8 ph[NS], pl_[NS];
+#pragma unroll
+        for (int ss = 0; ss < NS; ++ss)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                _Float16 h0, l0, h1 = (_Float16)0.f, l1 = (_Float16)0.f;
+                split_f32(s[2 * ss][r] * inv, h0, l0);
+                if (2 * ss + 1 < NT) split_f32(s[(2 * ss + 1 < NT) ? 2 * ss + 1 : 0][r] * inv, h1, l1);
+                ph[ss][r] = h0; pl_[ss][r] = l0; ph[ss][4 + r] = h1; pl_[ss][4 + r] = l1;
+            }
+        f32x4 om[DT], ox[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) { om[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; ox[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int ss = 0; ss < NS; ++ss) {
+            // keys 32 ss + 4g + q (elements 0-3) and 32 ss + 16 + 4g + q (elements 4-7); a missing odd tile re-reads the even one (P = 0)
+            const int ra = 32 * ss + 4 * g + q, rb = (2 * ss + 1 < NT) ? ra + 16 : ra;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const int chn = dt * 2 + (pp >> 1), sub = (pp & 1) * 8;
+                const size_t oa = ((size_t)ra * CH + (chn ^ (ra & 7))) * 16 + sub, ob = ((size_t)rb * CH + (chn ^ (rb & 7))) * 16 + sub;
+                trvec h0 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) trvec*)(vs3 + oa));
+                trvec h1 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) trvec*)(vs3 + ob));
+                trvec l0 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) trvec*)(vs3 + PLB + oa));
+                trvec l1 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) trvec*)(vs3 + PLB + ob));
+                f16x8 vh, vl;
+                __builtin_memcpy(&vh, &h0, 8);
+                __builtin_memcpy((char*)&vh + 8, &h1, 8);
+                __builtin_memcpy(&vl, &l0, 8);
+                __builtin_memcpy((char*)&vl + 8, &l1, 8);
+                ox[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, pl_[ss], ox[dt], 0, 0, 0);
+                om[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, ph[ss], om[dt], 0, 0, 0);
+                ox[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl, ph[ss], ox[dt], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (qrow < T) {
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaf(ox[dt][r], SPLIT_LO_INV, om[dt][r]);
+                store_h_rt<4>(ctx, ((long)b * T + qrow) * H + head * D + dt * 16 + g * 4, ctx_lo, v);
+            }
+        }
+    }
+}
+
 }  // namespace advh
 
 using namespace advh;
@@ -570,6 +694,11 @@ int advh_init_attention() {
                             (int)att_x3_lds(NT_, D_)) != hipSuccess) return ADVH_ELAUNCH;
     X3A(4, 32) X3A(8, 32) X3A(13, 32) X3A(16, 32) X3A(4, 64) X3A(8, 64) X3A(13, 64) X3A(16, 64)
 #undef X3A
+#define X3T(NT_)                                                                                                                    \
+    if (hipFuncSetAttribute((const void*)attention_x3_tr_kernel<NT_>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * NT_ * 16 * 64 * 2) != hipSuccess) \
+        return ADVH_ELAUNCH;
+    X3T(4) X3T(8) X3T(13) X3T(16)
+#undef X3T
     if (hipFuncSetAttribute((const void*)attention_x3_stream_kernel<7, 128>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)att_x3_lds(7, 128)) != hipSuccess) return ADVH_ELAUNCH;
     return ADVH_OK;
@@ -590,6 +719,12 @@ extern "C" int advh_attention_split(const void* qkv, int64_t qkv_lo, void* ctx, 
     dim3 grid(heads, B);
     hipStream_t s = (hipStream_t)stream;
     const int nt = (T + 15) / 16;
+    if (dm == 64) {                                      // row-major DMA staging + transposing V^T reads
+#define ATTXT(NT_) hipLaunchKernelGGL((attention_x3_tr_kernel<NT_>), grid, dim3(512), 4 * NT_ * 16 * 64 * 2, s, (const _Float16*)qkv, (long)qkv_lo, (_Float16*)ctx, (long)ctx_lo, T, H, scale)
+        if (nt <= 4) ATTXT(4); else if (nt <= 8) ATTXT(8); else if (nt <= 13) ATTXT(13); else ATTXT(16);
+#undef ATTXT
+        return ADVH_LAUNCH_CHECK();
+    }
 #define ATTX(NT_, D_) hipLaunchKernelGGL((attention_x3_kernel<NT_, D_>), grid, dim3(512), att_x3_lds(NT_, D_), s, (const _Float16*)qkv, (long)qkv_lo, (_Float16*)ctx, (long)ctx_lo, T, H, dm, scale)
     if (D == 64) { if (nt <= 4) ATTX(4, 64); else if (nt <= 8) ATTX(8, 64); else if (nt <= 13) ATTX(13, 64); else ATTX(16, 64); }
     else { if (nt <= 4) ATTX(4, 32); else if (nt <= 8) ATTX(8, 32); else if (nt <= 13) ATTX(13, 32); else ATTX(16, 32); }
