@@ -68,6 +68,8 @@ def parse_args():
     ap.add_argument("--cpu-repeats", type=int, default=3)
     ap.add_argument("--cpu-threads", type=int, default=0, help="host threads for the CPU baseline (0 = every core this process may use)")
     ap.add_argument("--master-port", type=int, default=0)
+    ap.add_argument("--no-traffic", action="store_true",
+                    help="skip the two child rocprofv3 --pmc passes that measure the dominant kernel's HBM bytes per launch")
     return ap.parse_args()
 
 
@@ -228,6 +230,45 @@ def gemm_roofline(G, precision, tuned=False):
             "gflop_per_launch": None if not n else round(flops / n / 1e9, 2)}
 
 
+def measured_traffic(kernel, precision):
+    """HBM bytes per launch of `kernel`, measured NOW: two child runs of this script under `rocprofv3 --pmc` (FETCH_SIZE and
+    WRITE_SIZE in separate passes with --kernel-trace only, as MI355X_MICROARCH.md's HBM section prescribes; FETCH_SIZE x2:
+    gfx950 counts 128-byte requests as 64; both counters in KiB), started as child processes after the timed region (the
+    parent never execs).  Returns (bytes, source) or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None, "rocprofv3 not on PATH"
+    tot = {}
+    tmp = tempfile.mkdtemp(prefix="advh_pmc_", dir=os.environ.get("TMPDIR", "/tmp"))
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable,
+                   os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extras", "--no-traffic",
+                   "--precision", precision]
+            r = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600, env=dict(os.environ, TMPDIR="/tmp"))
+            vals = []
+            for fn in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                with open(fn) as fh:
+                    for row in csv.DictReader(fh):
+                        if row["Counter_Name"] == counter and kernel in row["Kernel_Name"]:
+                            vals.append(float(row["Counter_Value"]))
+            if r.returncode != 0 or not vals:
+                return None, f"rocprofv3 --pmc {counter} pass failed (rc {r.returncode}, {len(vals)} samples)"
+            tot[counter] = sum(vals) / len(vals)
+        nbytes = 2.0 * tot["FETCH_SIZE"] * 1024 + tot["WRITE_SIZE"] * 1024
+        return round(nbytes), ("measured in this invocation: two child `rocprofv3 --pmc` passes of `bench.py --steps 2` (FETCH_SIZE x2 + WRITE_SIZE, "
+                               "KiB -> bytes, mean per launch of the dominant kernel)")
+    except Exception as e:                               # profiling must never take the benchmark line down
+        return None, f"traffic measurement failed: {type(e).__name__}: {e}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def committed_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE collected in
     separate runs of this same command, tools/pmc_bench_traffic.sh).  PMC counters cannot be read from inside an unprofiled
@@ -266,6 +307,13 @@ def explain_line(ctx):
         "cpu_baseline": None,
     }
     extras = world == 1 and not args.no_extras and not args.tune
+    if rank == 0 and world == 1 and not args.no_traffic and not args.tune and head["roofline"]["launches"]:
+        kern = head["roofline"]["kernel"]
+        nbytes, src = measured_traffic(kern, args.precision)
+        if nbytes is not None:
+            line["roofline"]["traffic"], line["roofline"]["traffic_source"] = nbytes, src
+        else:
+            line["roofline"]["traffic_source"] = f"{src}; falling back to " + str(line["roofline"]["traffic_source"])
     if extras:
         other = "f16" if args.precision == "f32" else "f32"
         o = run_explain(ctx, other, args.steps, args.warmup)

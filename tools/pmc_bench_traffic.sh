@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   d=gpurun_out/pmc_bench_$c
   rm -rf $d
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $d -o p -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras ${BENCH_ARGS} > /dev/null 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $d -o p -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --no-traffic ${BENCH_ARGS} > /dev/null 2>&1
 done
 python3 - <<'PY'
 import csv, glob, json, collections

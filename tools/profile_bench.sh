@@ -6,6 +6,6 @@ tag=${1:-r02}
 export TMPDIR=/tmp
 out=$PWD/gpurun_out/prof_$tag
 mkdir -p "$out"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out" -o bench -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras ${BENCH_ARGS} > "$out/bench_stdout.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out" -o bench -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras --no-traffic ${BENCH_ARGS} > "$out/bench_stdout.log" 2>&1
 python3 tools/summarize_rocprof.py "$out" > "$out/kernel_summary.txt"
 cat "$out/kernel_summary.txt"
