@@ -188,3 +188,24 @@ def test_explain_edge_shapes_f32(gpu_device, B, n):
     assert torch.equal(out["mask"].cpu() > 0.5, ref["mask"] > 0.5)
     assert (out["wave_in"].cpu() - ref["wave_in"]).abs().max().item() <= 5e-5
     assert (out["wave_out"].cpu() - ref["wave_out"]).abs().max().item() <= 5e-5
+
+
+def test_full_batch_f32_mask_indices_match_oracle(gpu_device):
+    """BASELINE batch (64 x 4 s, wav2vec2-base + U-Net) in the fp32-class mode: for four clips spread over the batch the
+    `mask > 0.5` index set equals the oracle's bit for bit and the three probabilities agree to 1e-4 (the oracle runs those
+    four clips only; sub-batch bit-equality, tested above, covers the rest of the batch)."""
+    cfg = syn.base_config()
+    emb_sd, unet_sd = syn.embedder_weights(cfg), syn.unet_weights()
+    coef, icpt = syn.logreg_weights(cfg.hidden_size)
+    pipe = P.ExplainPipeline(cfg, emb_sd, coef, icpt, unet_sd, gpu_device, audio_length=4, precision="f32")
+    w = syn.make_clips(64, 64000)
+    out = pipe.explain(w.to(gpu_device))
+    pick = [0, 21, 42, 63]
+    ref = lmac_ref.explain(w[pick], emb_sd, cfg, coef, icpt, unet_sd, audio_length=4)
+    mask = out["mask"][pick].cpu()
+    flips = int(((mask > 0.5) != (ref["mask"] > 0.5)).sum())
+    print(f"full batch f32: mask max err {(mask - ref['mask']).abs().max():.3e}, index flips {flips} of {mask.numel()}, "
+          f"closest reference value to 0.5: {(ref['mask'] - 0.5).abs().min():.2e}")
+    assert flips == 0
+    for k in ("predictions", "theta_out", "masked_predictions"):
+        assert (out[k][pick].cpu() - ref[k]).abs().max().item() <= 1e-4, k
