@@ -7,6 +7,7 @@ import sys
 from collections import defaultdict
 
 root = sys.argv[1]
+by_grid = "--by-grid" in sys.argv          # split each kernel by its grid size (one GEMM instance serves several shapes)
 files = glob.glob(os.path.join(root, "**", "*kernel_trace.csv"), recursive=True)
 if not files:
     sys.exit("no kernel_trace.csv under " + root)
@@ -15,6 +16,9 @@ for f in files:
     with open(f) as fh:
         for row in csv.DictReader(fh):
             name = row.get("Kernel_Name") or row.get("kernel_name")
+            if by_grid:
+                wg = max(1, int(row.get("Workgroup_Size_X") or 1))
+                name = f"[{int(row.get('Grid_Size_X') or 0) // wg:>6d} x{row.get('Grid_Size_Z') or 1} wg] " + name
             dur = float(row["End_Timestamp"]) - float(row["Start_Timestamp"])
             a = agg[name]
             a[0] += 1

@@ -34,7 +34,7 @@ TILE_NAMES = {TILE_128x128: "128x128", TILE_256x64: "256x64", TILE_256x32: "256x
               TILE_256x128_W4: "256x128w4", TILE_128x256_W4: "128x256w4", TILE_256x256_RING: "256x256r",
               TILE_256x128_W8: "256x128w8", TILE_128x256_W8: "128x256w8", TILE_256x128_PERSIST: "256x128ps", TILE_256x256_W4: "256x256w4"}
 # device symbol (as rocprofv3 prints it) of the kernels the live profile covers
-TILE_KERNELS = {TILE_128x128: "gemm_f16_kernel<128, 128, 2, 2, 3>", TILE_128x256_W8: "gemm_f16_kernel<128, 256, 2, 4, 3>",
+TILE_KERNELS = {TILE_128x128: "gemm_f16_kernel<128, 128, 2, 2, 4>", TILE_128x256_W8: "gemm_f16_kernel<128, 256, 2, 4, 3>",
                 TILE_256x128_W8: "gemm_f16_kernel<256, 128, 4, 2, 3>", TILE_256x256: "gemm_f16_pipe_kernel<256, 256, 2, 4, 2>",
                 TILE_256x128: "gemm_f16_pipe_kernel<256, 128, 4, 2, 3>", TILE_256x128_PERSIST: "gemm_f16_persist_kernel<256, 128, 4, 2>"}
 

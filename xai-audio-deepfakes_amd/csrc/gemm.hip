@@ -34,6 +34,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 
 constexpr int BK = 64;          // halfs per K-step = 8 chunks of 16 B
+#ifdef ADVH_STAMPS                // diagnostic build only (-DADVH_STAMPS): core-clock and 100 MHz stamps around one workgroup of the x3 / fp16 tiles
+__device__ long long g_gemm_stamps[8];
+__device__ long long g_kstep[8];               // wave 0 of the mid-grid workgroup, K-step 6: core-clock stamps inside the step
+__device__ long long g_wg_rec[4 * 16384];   // per workgroup of the last x3 launch: start, K loop end, end (100 MHz ticks), HW_ID | XCC_ID << 32
+#endif
 
 // ds_read_b128 the compiler does not track (see the pipelined kernel) and the matching counted wait
 #define DS_READ128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
@@ -227,9 +232,294 @@ __device__ __forceinline__ void gemm_epilogue_lean(const advh_gemm_desc& p, f32x
     }
 }
 
+// bias of the NQ groups of 8 consecutive channels n, n + 32, ... a lane owns in the wide layout (zeros without a bias)
+template <int NQ>
+__device__ __forceinline__ void load_bias8(const advh_gemm_desc& p, int z, int n0, float (&bb)[NQ][8]) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) bb[q][k] = 0.f;
+    if (!p.bias) return;
+    const float* bias = p.bias + (long)p.bias_sZ * z;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int n = n0 + q * 32;
+        const float4 b0 = *(const float4*)(bias + (n < p.N ? n : 0)), b1 = *(const float4*)(bias + (n < p.N ? n : 0) + 4);
+        bb[q][0] = b0.x; bb[q][1] = b0.y; bb[q][2] = b0.z; bb[q][3] = b0.w;
+        bb[q][4] = b1.x; bb[q][5] = b1.y; bb[q][6] = b1.z; bb[q][7] = b1.w;
+    }
+}
+
+// Tight form of the lean epilogue: the three shapes the Linear layers of the embedder use, each compiled as its own
+// straight-line code (MODE 0: bias -> fp16-side output; 1: bias + GELU -> fp16-side output; 2: bias + fp32 residual
+// -> fp32 output, the residual stream).  The general forms below test every descriptor option per value group, which
+// unrolls to ~30 000 instructions (~200 KiB) per kernel: skipping through that text costs an instruction-cache miss per
+// taken branch -- measured 16 500 cycles per workgroup (a quarter of a K = 768 tile) against ~3 000 here.
+// PRE = rows whose residual is loaded before the first store (out == resid, so a load cannot pass an earlier store).
+template <int MI, int NI, bool SPLIT, int MODE, int PRE>
+__device__ __forceinline__ void gemm_epilogue_tight(const advh_gemm_desc& p, f32x4 (&acc)[NI][MI], int mw0, int nw0, int fr, int fq, int z,
+                                                    long zo) {
+    constexpr int NQ = NI / 2;
+    static_assert(MI % PRE == 0, "residual rows per group");
+    float bb[NQ][8];
+    load_bias8<NQ>(p, z, nw0 + fq * 8, bb);
+#pragma unroll
+    for (int g = 0; g < MI; g += PRE) {
+        float rv[MODE == 2 ? PRE : 1][NQ][8];
+        if constexpr (MODE == 2) {
+#pragma unroll
+            for (int i = 0; i < PRE; ++i) {
+                const int m = min(mw0 + (g + i) * 16 + fr, p.M - 1);
+                const long orow = (long)m * p.o_sW + p.o_c0 + zo;
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    const int n = nw0 + q * 32 + fq * 8;
+                    const float* r = (const float*)p.resid + orow + (n < p.N ? n : 0);
+                    const float4 r0 = *(const float4*)r, r1 = *(const float4*)(r + 4);
+                    rv[i][q][0] = r0.x; rv[i][q][1] = r0.y; rv[i][q][2] = r0.z; rv[i][q][3] = r0.w;
+                    rv[i][q][4] = r1.x; rv[i][q][5] = r1.y; rv[i][q][6] = r1.z; rv[i][q][7] = r1.w;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < PRE; ++i) {
+            const int mi = g + i, m = mw0 + mi * 16 + fr;
+            if (m >= p.M) continue;
+            const long orow = (long)m * p.o_sW + p.o_c0 + zo;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int n = nw0 + q * 32 + fq * 8;
+                if (n >= p.N) continue;
+                float v[8];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { v[r] = acc[2 * q][mi][r] + bb[q][r]; v[4 + r] = acc[2 * q + 1][mi][r] + bb[q][4 + r]; }
+                if constexpr (MODE == 1) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) v[r] = gelu_fast(v[r]);
+                }
+                if constexpr (MODE == 2) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) v[r] += rv[i][q][r];
+                    float* o = (float*)p.out_f + orow + n;
+                    *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
+                    *(float4*)(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                } else {
+                    store_h<8, SPLIT>(p.out_h, orow + n, p.o_lo, v);
+                }
+            }
+        }
+    }
+}
+
+// Staged form of tight modes 0 / 1 for a 64-column wavefront tile: the wavefront writes its (16 MI) x 64 tile (one
+// plane, or hi + lo planes) into the LDS the K loop no longer needs -- row-major, 16-byte chunks XOR-swizzled by the
+// row -- and reads it back with 8 lanes per row, so that a store instruction covers 8 rows x one full 128-byte line
+// instead of 16 rows x 64 bytes.  Wavefront-local (LDS operations of a wavefront complete in order): no barrier.
+// ACT: ADVH_ACT_*; ROWS: output row m lives at the (b, h, w) address of the general form (convolutions: window test,
+// halo_zero) instead of o_c0 + m * o_sW.
+template <int MI, int NI, bool SPLIT, int ACT, bool ROWS = false>
+__device__ __forceinline__ void gemm_epilogue_staged(const advh_gemm_desc& p, f32x4 (&acc)[NI][MI], char* stage, int mw0, int nw0, int lane,
+                                                     int z, long zo) {
+    static_assert(NI == 4, "64-column wavefront tile, fp16-side output");
+    constexpr int PL = MI * 16 * 128;                          // bytes of one plane of the wavefront's tile
+    const int fr = lane & 15, fq = lane >> 4;
+    float bb[2][8];
+    load_bias8<2>(p, z, nw0 + fq * 8, bb);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int r = mi * 16 + fr;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { v[k] = acc[2 * q][mi][k] + bb[q][k]; v[4 + k] = acc[2 * q + 1][mi][k] + bb[q][4 + k]; }
+            if constexpr (ACT == ADVH_ACT_GELU) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = gelu_fast(v[k]);
+            }
+            if constexpr (ACT == ADVH_ACT_LEAKY) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = v[k] > 0.f ? v[k] : p.slope * v[k];
+            }
+            char* dst = stage + r * 128 + (((q * 4 + fq) ^ (r & 7)) << 4);
+            f16x8 hv, lv;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if constexpr (SPLIT) { _Float16 h, l; split_f32(v[k], h, l); hv[k] = h; lv[k] = l; }
+                else hv[k] = (_Float16)v[k];
+            }
+            *(f16x8*)dst = hv;
+            if constexpr (SPLIT) *(f16x8*)(dst + PL) = lv;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int rr = lane >> 3, c = lane & 7, n = nw0 + c * 8;
+    _Float16* out = (_Float16*)p.out_h;
+    unsigned Wg = p.Wg, Hg = p.Hg;
+    asm volatile("" : "+s"(Wg), "+s"(Hg));                 // the reciprocals are computed here, not hoisted above the K loop
+    const RowDecomp rd(Wg, Hg);
+#pragma unroll
+    for (int it = 0; it < MI * 2; ++it) {
+        const int row = it * 8 + rr, m = mw0 + row;
+        const char* src = stage + row * 128 + ((c ^ (row & 7)) << 4);
+        f16x8 hv = *(const f16x8*)src;
+        f16x8 lv;
+        if constexpr (SPLIT) lv = *(const f16x8*)(src + PL);
+        if (m < p.M && n < p.N) {
+            long o;
+            if constexpr (ROWS) {
+                unsigned w, h, b;
+                rd((unsigned)m, b, h, w);
+                const bool ok = (int)h >= p.h0 && (int)h < p.h1 && (int)w >= p.w0 && (int)w < p.w1;
+                if (!ok && !p.halo_zero) continue;
+                if (!ok) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) { hv[k] = (_Float16)0.f; lv[k] = (_Float16)0.f; }
+                }
+                o = (long)b * p.o_sB + (long)h * p.o_sH + (long)w * p.o_sW + p.o_c0 + zo + n;
+            } else {
+                o = (long)m * p.o_sW + p.o_c0 + zo + n;
+            }
+            *(f16x8*)(out + o) = hv;
+            if constexpr (SPLIT) *(f16x8*)(out + o + p.o_lo) = lv;
+        }
+        if constexpr (ROWS && !SPLIT) {
+            if (it & 1) __builtin_amdgcn_sched_barrier(0);     // keep two rows' address arithmetic in flight, not eight: the fp16 kernels' 4 wavefronts per SIMD need <= 128 VGPRs
+        }
+    }
+}
+
+// Tight form of the general (row-decomposing) epilogue for what every convolution of the forward path asks for: wide
+// packing, one column block, bias (or none) + activation -> fp16-side output; window test and halo_zero as in the general form.
+template <int MI, int NI, bool SPLIT, int ACT>
+__device__ __forceinline__ void gemm_epilogue_rows_tight(const advh_gemm_desc& p, f32x4 (&acc)[NI][MI], int mw0, int nw0, int fr, int fq, int z,
+                                                         long zo) {
+    constexpr int NQ = NI / 2;
+    float bb[NQ][8];
+    load_bias8<NQ>(p, z, nw0 + fq * 8, bb);
+    const RowDecomp rd(p.Wg, p.Hg);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const unsigned m = mw0 + mi * 16 + fr;
+        if (m >= (unsigned)p.M) continue;
+        unsigned w, h, b;
+        rd(m, b, h, w);
+        const bool ok = (int)h >= p.h0 && (int)h < p.h1 && (int)w >= p.w0 && (int)w < p.w1;
+        if (!ok && !p.halo_zero) continue;
+        const long orow = (long)b * p.o_sB + (long)h * p.o_sH + (long)w * p.o_sW + p.o_c0 + zo;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int n = nw0 + q * 32 + fq * 8;
+            if (n >= p.N) continue;
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { v[k] = acc[2 * q][mi][k] + bb[q][k]; v[4 + k] = acc[2 * q + 1][mi][k] + bb[q][4 + k]; }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if constexpr (ACT == ADVH_ACT_GELU) v[k] = gelu_fast(v[k]);
+                if constexpr (ACT == ADVH_ACT_LEAKY) v[k] = v[k] > 0.f ? v[k] : p.slope * v[k];
+                if (!ok) v[k] = 0.f;
+            }
+            store_h<8, SPLIT>(p.out_h, orow + n, p.o_lo, v);
+        }
+    }
+}
+
+// Staged form of tight mode 2 (fp32 residual stream, out_f = resid + acc + bias) for the fp32-class kernels, whose
+// wavefront owns 16 KiB of LDS: the residual is prefetched in the store layout (16 lanes x float4 per row), the tile
+// goes through LDS as fp32 (16-byte chunks XOR-swizzled by the row), and every load / store instruction covers
+// 4 rows x 256 contiguous bytes instead of 16 rows x 128.
+template <int MI, int NI>
+__device__ __forceinline__ void gemm_epilogue_staged_f32(const advh_gemm_desc& p, f32x4 (&acc)[NI][MI], char* stage, int mw0, int nw0, int lane,
+                                                         int z, long zo) {
+    static_assert(NI == 4, "64-column wavefront tile");
+    const int fr = lane & 15, fq = lane >> 4;
+    const int rr = lane >> 4, c = lane & 15, n = nw0 + c * 4;
+    float4 rv[MI * 4];
+#pragma unroll
+    for (int it = 0; it < MI * 4; ++it) {
+        const int m = min(mw0 + it * 4 + rr, p.M - 1);
+        rv[it] = *(const float4*)((const float*)p.resid + (long)m * p.o_sW + p.o_c0 + zo + (n < p.N ? n : 0));
+    }
+    float bb[2][8];
+    load_bias8<2>(p, z, nw0 + fq * 8, bb);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int r = mi * 16 + fr;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int ch = 2 * (q * 4 + fq);
+            *(float4*)(stage + r * 256 + ((ch ^ (r & 15)) << 4)) =
+                make_float4(acc[2 * q][mi][0] + bb[q][0], acc[2 * q][mi][1] + bb[q][1], acc[2 * q][mi][2] + bb[q][2], acc[2 * q][mi][3] + bb[q][3]);
+            *(float4*)(stage + r * 256 + (((ch + 1) ^ (r & 15)) << 4)) =
+                make_float4(acc[2 * q + 1][mi][0] + bb[q][4], acc[2 * q + 1][mi][1] + bb[q][5], acc[2 * q + 1][mi][2] + bb[q][6], acc[2 * q + 1][mi][3] + bb[q][7]);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < MI * 4; ++it) {
+        const int row = it * 4 + rr, m = mw0 + row;
+        const float4 v = *(const float4*)(stage + row * 256 + ((c ^ (row & 15)) << 4));
+        if (m < p.M && n < p.N)
+            *(float4*)((float*)p.out_f + (long)m * p.o_sW + p.o_c0 + zo + n) = make_float4(v.x + rv[it].x, v.y + rv[it].y, v.z + rv[it].z, v.w + rv[it].w);
+    }
+}
+
+// which tight form serves this descriptor (-1: none); uniform, evaluated once per workgroup
+__device__ __forceinline__ int tight_mode(const advh_gemm_desc& p) {
+    if (!p.wide || p.out_pre || p.dact_src || p.out_h2) return -1;
+    if (p.out_h && !p.out_f && !p.resid) return p.act == ADVH_ACT_NONE ? 0 : p.act == ADVH_ACT_GELU ? 1 : -1;
+    if (p.out_f && !p.out_h && p.resid && p.resid_f32 && p.act == ADVH_ACT_NONE) return 2;
+    return -1;
+}
+
+// stage: this wavefront's 16 MI x 64 x 2 (x 2 planes) bytes of LDS, free once the K loop's last barrier has passed
+// (nullptr: the tile shape has no staged form)
+template <int MI, int NI, bool SPLIT, int PRE>
+__device__ __forceinline__ void gemm_epilogue_plain(const advh_gemm_desc& p, f32x4 (&acc)[NI][MI], char* stage, int mw0, int nw0, int fr, int fq,
+                                                    int z, long zo) {
+    const int mode = tight_mode(p);
+    if constexpr (NI == 4) {
+        if (stage && mode == 0) return gemm_epilogue_staged<MI, NI, SPLIT, 0>(p, acc, stage, mw0, nw0, fr + 16 * fq, z, zo);
+        if (stage && mode == 1) return gemm_epilogue_staged<MI, NI, SPLIT, 1>(p, acc, stage, mw0, nw0, fr + 16 * fq, z, zo);
+        if constexpr (SPLIT) {                              // the fp32-class kernels' stage holds the wavefront's tile as fp32 too
+            if (stage && mode == 2) return gemm_epilogue_staged_f32<MI, NI>(p, acc, stage, mw0, nw0, fr + 16 * fq, z, zo);
+        }
+    }
+    if (mode == 0) gemm_epilogue_tight<MI, NI, SPLIT, 0, PRE>(p, acc, mw0, nw0, fr, fq, z, zo);
+    else if (mode == 1) gemm_epilogue_tight<MI, NI, SPLIT, 1, PRE>(p, acc, mw0, nw0, fr, fq, z, zo);
+    else if (mode == 2) gemm_epilogue_tight<MI, NI, SPLIT, 2, PRE>(p, acc, mw0, nw0, fr, fq, z, zo);
+    else gemm_epilogue_lean<MI, NI, SPLIT>(p, acc, mw0, nw0, fr, fq, z, zo);
+}
+
 template <int MI, int NI, bool SPLIT = false>
 __device__ __forceinline__ void gemm_epilogue(const advh_gemm_desc& p, f32x4 (&acc)[NI][MI], int mw0, int nw0, int fr, int fq, int z,
-                                              long zo = -1) {          // zo: output offset of batch z (default o_sZ * z)
+                                              long zo = -1);            // zo: output offset of batch z (default o_sZ * z)
+
+// the row-decomposing epilogue of the two single-buffered kernels: staged / tight form where the descriptor allows, else general
+template <int MI, int NI, bool SPLIT>
+__device__ __forceinline__ void gemm_epilogue_rows(const advh_gemm_desc& p, f32x4 (&acc)[NI][MI], char* stage, int mw0, int nw0, int fr, int fq,
+                                                   int z, long zo) {
+    const bool simple = p.wide && p.n_div >= p.N && p.ph_r <= 0 && p.out_h && !p.out_f && !p.resid && !p.out_pre && !p.dact_src && !p.out_h2;
+    if (simple) {
+        if constexpr (NI == 4) {
+            if (stage) {
+                if (p.act == ADVH_ACT_LEAKY) return gemm_epilogue_staged<MI, NI, SPLIT, ADVH_ACT_LEAKY, true>(p, acc, stage, mw0, nw0, fr + 16 * fq, z, zo);
+                if (p.act == ADVH_ACT_GELU) return gemm_epilogue_staged<MI, NI, SPLIT, ADVH_ACT_GELU, true>(p, acc, stage, mw0, nw0, fr + 16 * fq, z, zo);
+                return gemm_epilogue_staged<MI, NI, SPLIT, ADVH_ACT_NONE, true>(p, acc, stage, mw0, nw0, fr + 16 * fq, z, zo);
+            }
+        }
+        if (p.act == ADVH_ACT_LEAKY) return gemm_epilogue_rows_tight<MI, NI, SPLIT, ADVH_ACT_LEAKY>(p, acc, mw0, nw0, fr, fq, z, zo);
+        if (p.act == ADVH_ACT_GELU) return gemm_epilogue_rows_tight<MI, NI, SPLIT, ADVH_ACT_GELU>(p, acc, mw0, nw0, fr, fq, z, zo);
+        return gemm_epilogue_rows_tight<MI, NI, SPLIT, ADVH_ACT_NONE>(p, acc, mw0, nw0, fr, fq, z, zo);
+    }
+    gemm_epilogue<MI, NI, SPLIT>(p, acc, mw0, nw0, fr, fq, z, zo);
+}
+
+template <int MI, int NI, bool SPLIT>
+__device__ __forceinline__ void gemm_epilogue(const advh_gemm_desc& p, f32x4 (&acc)[NI][MI], int mw0, int nw0, int fr, int fq, int z, long zo) {
     static_assert(NI % 2 == 0, "the wide epilogue pairs n-tiles");
     const float* bias = p.bias ? p.bias + (long)p.bias_sZ * z : nullptr;
     const RowDecomp rd(p.Wg, p.Hg);
@@ -444,8 +734,9 @@ __global__ __launch_bounds__(64 * WM * WN, WPE) void gemm_f16_kernel(const advh_
         __syncthreads();
     }
 
-    if (PLAIN && p.plain_out) gemm_epilogue_lean<MI, NI>(p, acc, m0 + wm * TM, n0 + wn * TN, fr, fq, z, p.o_sZ * zh + p.o_sZ2 * zw);
-    else gemm_epilogue<MI, NI>(p, acc, m0 + wm * TM, n0 + wn * TN, fr, fq, z, p.o_sZ * zh + p.o_sZ2 * zw);
+    char* stage = (NI == 4 && MI * 16 * 128 * WM * WN <= (BM + BN) * BK * 2) ? smem + wv * (MI * 16 * 128) : nullptr;
+    if (PLAIN && p.plain_out) gemm_epilogue_plain<MI, NI, false, 1>(p, acc, stage, m0 + wm * TM, n0 + wn * TN, fr, fq, z, p.o_sZ * zh + p.o_sZ2 * zw);
+    else gemm_epilogue_rows<MI, NI, false>(p, acc, stage, m0 + wm * TM, n0 + wn * TN, fr, fq, z, p.o_sZ * zh + p.o_sZ2 * zw);
 }
 
 template <int BM, int BN, int WM, int WN, int WPE>
@@ -455,7 +746,7 @@ static int launch(const advh_gemm_desc& d, hipStream_t s) {
     const int nz = d.nz > 0 ? d.nz : 1;
     if (d.z_inner && (long)tilesM * tilesN * nz > 0x7fffffffL) return ADVH_EINVAL;
     dim3 grid(d.z_inner ? tilesM * tilesN * nz : tilesM * tilesN, 1, d.z_inner ? 1 : nz);
-    if constexpr (BM == 128 && BN == 128 && WPE == 3) {
+    if constexpr (BM == 128 && BN == 128 && WPE == 4) {
         if (d.plain) {
             hipLaunchKernelGGL((gemm_f16_kernel<BM, BN, WM, WN, WPE, true>), grid, dim3(64 * WM * WN), 0, s, d);
             return ADVH_LAUNCH_CHECK();
@@ -483,6 +774,13 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_x3_kernel(const advh_gem
     constexpr int PA = BM * BK * 2, PB = BN * BK * 2;   // bytes of one plane of a K-step
     static_assert(NA >= 1 && NB >= 1 && BM % RPP == 0 && BN % RPP == 0, "loader passes");
     extern __shared__ __attribute__((aligned(16))) char dsm3[];
+#ifdef ADVH_STAMPS
+    if (blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) g_gemm_stamps[4] = __builtin_amdgcn_s_memtime();
+    if (threadIdx.x == 0 && blockIdx.x < 16384) {
+        g_wg_rec[4 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+        g_wg_rec[4 * blockIdx.x + 3] = (long long)__builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11)) | ((long long)__builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11)) << 32);
+    }
+#endif
     char* ldsA = dsm3;                                  // [A hi | A lo | W hi | W lo]
     char* ldsB = dsm3 + 2 * PA;
 
@@ -569,7 +867,20 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_x3_kernel(const advh_gem
 
     const int nk = p.Ktot / BK;
     int kq = PLAIN ? 0 : p.ktab[q];
+#ifdef STAGGER
+    if (blockIdx.x >= 256 && blockIdx.x < 512 && gridDim.x >= 1024) {
+        const long long t0 = __builtin_amdgcn_s_memtime();
+        while (__builtin_amdgcn_s_memtime() - t0 < (long long)nk * STAGGER) __builtin_amdgcn_s_sleep(16);
+    }
+#endif
+#ifdef ADVH_STAMPS
+    if (blockIdx.x == gridDim.x / 2 && tid == 0) { g_gemm_stamps[0] = __builtin_amdgcn_s_memtime(); g_gemm_stamps[1] = __builtin_amdgcn_s_memrealtime(); }
+#endif
     for (int kt = 0; kt < nk; ++kt) {
+#ifdef ADVH_STAMPS
+        if (blockIdx.x == gridDim.x / 2 && tid == 0 && kt == 6) g_kstep[0] = __builtin_amdgcn_s_memtime();
+        if (blockIdx.x == gridDim.x / 2 && tid == 0 && kt == 7) g_kstep[5] = __builtin_amdgcn_s_memtime();
+#endif
         if constexpr (PLAIN) {
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
@@ -599,8 +910,18 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_x3_kernel(const advh_gem
             }
             if (kt + 1 < nk) kq = p.ktab[(kt + 1) * 8 + q];
         }
+#ifdef ADVH_STAMPS
+        const bool stamp_here = blockIdx.x == gridDim.x / 2 && tid == 0 && kt == 6;
+        if (stamp_here) g_kstep[1] = __builtin_amdgcn_s_memtime();     // DMA issued
+#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef ADVH_STAMPS
+        if (stamp_here) g_kstep[2] = __builtin_amdgcn_s_memtime();     // this wavefront's DMA landed
+#endif
         __syncthreads();
+#ifdef ADVH_STAMPS
+        if (stamp_here) g_kstep[3] = __builtin_amdgcn_s_memtime();     // barrier passed
+#endif
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             f16x8 bh[NI], bl[NI];
@@ -621,8 +942,15 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_x3_kernel(const advh_gem
                 for (int ni = 0; ni < NI; ++ni) accx[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[ni], ah, accx[ni][mi], 0, 0, 0);
             }
         }
+#ifdef ADVH_STAMPS
+        if (stamp_here) g_kstep[4] = __builtin_amdgcn_s_memtime();     // MFMAs issued
+#endif
         __syncthreads();
     }
+#ifdef ADVH_STAMPS
+    if (blockIdx.x == gridDim.x / 2 && tid == 0) { g_gemm_stamps[2] = __builtin_amdgcn_s_memtime(); g_gemm_stamps[3] = __builtin_amdgcn_s_memrealtime(); }
+    if (tid == 0 && blockIdx.x < 16384) g_wg_rec[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+#endif
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
@@ -630,9 +958,20 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_x3_kernel(const advh_gem
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[ni][mi][r] = fmaf(accx[ni][mi][r], SPLIT_LO_INV, acc[ni][mi][r]);
 
-    if (PLAIN && p.plain_out) gemm_epilogue_lean<MI, NI, true>(p, acc, m0 + wm * TM, n0 + wn * TN, fr, fq, z, p.o_sZ * zh + p.o_sZ2 * zw);
-    else gemm_epilogue<MI, NI, true>(p, acc, m0 + wm * TM, n0 + wn * TN, fr, fq, z, p.o_sZ * zh + p.o_sZ2 * zw);
+#ifdef ADVH_STAMPS
+    if (blockIdx.x == gridDim.x / 2 && tid == 0) g_gemm_stamps[6] = __builtin_amdgcn_s_memtime();
+#endif
+    char* stage = (NI == 4 && MI * 16 * 256 * WM * WN <= 2 * (BM + BN) * BK * 2) ? dsm3 + wv * (MI * 16 * 256) : nullptr;
+    if (PLAIN && p.plain_out) gemm_epilogue_plain<MI, NI, true, MI>(p, acc, stage, m0 + wm * TM, n0 + wn * TN, fr, fq, z, p.o_sZ * zh + p.o_sZ2 * zw);
+    else gemm_epilogue_rows<MI, NI, true>(p, acc, stage, m0 + wm * TM, n0 + wn * TN, fr, fq, z, p.o_sZ * zh + p.o_sZ2 * zw);
+#ifdef ADVH_STAMPS
+    if (blockIdx.x == gridDim.x / 2 && tid == 0) g_gemm_stamps[7] = __builtin_amdgcn_s_memtime();
+    if (tid == 0 && blockIdx.x < 16384) g_wg_rec[4 * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (blockIdx.x == gridDim.x / 2 && tid == 0) g_gemm_stamps[5] = __builtin_amdgcn_s_memtime();
+#endif
 }
+
 
 template <int BM, int BN, int WM, int WN>
 static int launch_x3(const advh_gemm_desc& d, hipStream_t s) {
@@ -1147,6 +1486,12 @@ int advh_init_rest() {
     return ADVH_OK;
 }
 
+#ifdef ADVH_STAMPS
+extern "C" int advh_debug_wg_records(long long* out, int n) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wg_rec), sizeof(long long) * 4 * n) == hipSuccess ? ADVH_OK : ADVH_ELAUNCH; }
+extern "C" int advh_debug_kstep(long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_kstep), sizeof(long long) * 8) == hipSuccess ? ADVH_OK : ADVH_ELAUNCH; }
+extern "C" int advh_debug_gemm_stamps(long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gemm_stamps), sizeof(long long) * 8) == hipSuccess ? ADVH_OK : ADVH_ELAUNCH; }
+#endif
+
 extern "C" int advh_gemm_f16(const advh_gemm_desc* d, int tile, advh_stream_t stream) {
     if (!d || !d->A0 || !d->W || !d->ktab || (!d->out_h && !d->out_f)) return ADVH_EINVAL;
     if (d->w_rows < d->N || d->M <= 0 || d->N <= 0 || d->Ktot <= 0 || d->Ktot % BK || d->N % 4 || d->Hg <= 0 || d->Wg <= 0) return ADVH_EINVAL;
@@ -1173,7 +1518,7 @@ extern "C" int advh_gemm_f16(const advh_gemm_desc* d, int tile, advh_stream_t st
         }
     }
     switch (tile) {
-        case ADVH_TILE_128x128: return launch<128, 128, 2, 2, 3>(*d, s);
+        case ADVH_TILE_128x128: return launch<128, 128, 2, 2, 4>(*d, s);   // 4 wavefronts per SIMD: <= 128 VGPRs, checked spill-free
         case ADVH_TILE_256x64: return launch<256, 64, 4, 1, 3>(*d, s);
         case ADVH_TILE_256x32: return launch<256, 32, 4, 1, 3>(*d, s);
         case ADVH_TILE_256x128_W4: return launch<256, 128, 2, 2, 2>(*d, s);
