@@ -867,12 +867,6 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_x3_kernel(const advh_gem
 
     const int nk = p.Ktot / BK;
     int kq = PLAIN ? 0 : p.ktab[q];
-#ifdef STAGGER
-    if (blockIdx.x >= 256 && blockIdx.x < 512 && gridDim.x >= 1024) {
-        const long long t0 = __builtin_amdgcn_s_memtime();
-        while (__builtin_amdgcn_s_memtime() - t0 < (long long)nk * STAGGER) __builtin_amdgcn_s_sleep(16);
-    }
-#endif
 #ifdef ADVH_STAMPS
     if (blockIdx.x == gridDim.x / 2 && tid == 0) { g_gemm_stamps[0] = __builtin_amdgcn_s_memtime(); g_gemm_stamps[1] = __builtin_amdgcn_s_memrealtime(); }
 #endif
