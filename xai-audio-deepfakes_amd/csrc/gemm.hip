@@ -426,44 +426,53 @@ __device__ __forceinline__ void gemm_epilogue_rows_tight(const advh_gemm_desc& p
     }
 }
 
-// Staged form of tight mode 2 (fp32 residual stream, out_f = resid + acc + bias) for the fp32-class kernels, whose
-// wavefront owns 16 KiB of LDS: the residual is prefetched in the store layout (16 lanes x float4 per row), the tile
-// goes through LDS as fp32 (16-byte chunks XOR-swizzled by the row), and every load / store instruction covers
-// 4 rows x 256 contiguous bytes instead of 16 rows x 128.
-template <int MI, int NI>
+// Staged form of tight mode 2 (fp32 residual stream, out_f = resid + acc + bias): the residual is prefetched in the store
+// layout (16 lanes x float4 per row), the tile goes through LDS as fp32 (16-byte chunks XOR-swizzled by the row), and every
+// load / store instruction covers 4 rows x 256 contiguous bytes instead of 16 rows x 128.  PASSES: the wavefront's stage holds
+// 16 MI / PASSES rows of fp32 (fp32-class kernels: 16 KiB = the whole 64 x 64 tile, one pass; fp16 kernels: four passes of 16 rows, which keeps the prefetched residual at 16 VGPRs beside the 64 accumulators).
+template <int MI, int NI, int PASSES>
 __device__ __forceinline__ void gemm_epilogue_staged_f32(const advh_gemm_desc& p, f32x4 (&acc)[NI][MI], char* stage, int mw0, int nw0, int lane,
                                                          int z, long zo) {
-    static_assert(NI == 4, "64-column wavefront tile");
+    static_assert(NI == 4 && MI % PASSES == 0, "64-column wavefront tile");
+    constexpr int MP = MI / PASSES;                        // 16-row blocks per pass
     const int fr = lane & 15, fq = lane >> 4;
     const int rr = lane >> 4, c = lane & 15, n = nw0 + c * 4;
-    float4 rv[MI * 4];
-#pragma unroll
-    for (int it = 0; it < MI * 4; ++it) {
-        const int m = min(mw0 + it * 4 + rr, p.M - 1);
-        rv[it] = *(const float4*)((const float*)p.resid + (long)m * p.o_sW + p.o_c0 + zo + (n < p.N ? n : 0));
-    }
     float bb[2][8];
-    load_bias8<2>(p, z, nw0 + fq * 8, bb);
+    if constexpr (PASSES == 1) load_bias8<2>(p, z, nw0 + fq * 8, bb);
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-        const int r = mi * 16 + fr;
+    for (int ps = 0; ps < PASSES; ++ps) {
+        float4 rv[MP * 4];
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int ch = 2 * (q * 4 + fq);
-            *(float4*)(stage + r * 256 + ((ch ^ (r & 15)) << 4)) =
-                make_float4(acc[2 * q][mi][0] + bb[q][0], acc[2 * q][mi][1] + bb[q][1], acc[2 * q][mi][2] + bb[q][2], acc[2 * q][mi][3] + bb[q][3]);
-            *(float4*)(stage + r * 256 + (((ch + 1) ^ (r & 15)) << 4)) =
-                make_float4(acc[2 * q + 1][mi][0] + bb[q][4], acc[2 * q + 1][mi][1] + bb[q][5], acc[2 * q + 1][mi][2] + bb[q][6], acc[2 * q + 1][mi][3] + bb[q][7]);
+        for (int it = 0; it < MP * 4; ++it) {
+            const int m = min(mw0 + ps * MP * 16 + it * 4 + rr, p.M - 1);
+            rv[it] = *(const float4*)((const float*)p.resid + (long)m * p.o_sW + p.o_c0 + zo + (n < p.N ? n : 0));
         }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+        if constexpr (PASSES > 1) load_bias8<2>(p, z, nw0 + fq * 8, bb);   // per pass (an L1 hit behind the residual loads): 16 fewer live VGPRs
 #pragma unroll
-    for (int it = 0; it < MI * 4; ++it) {
-        const int row = it * 4 + rr, m = mw0 + row;
-        const float4 v = *(const float4*)(stage + row * 256 + ((c ^ (row & 15)) << 4));
-        if (m < p.M && n < p.N)
-            *(float4*)((float*)p.out_f + (long)m * p.o_sW + p.o_c0 + zo + n) = make_float4(v.x + rv[it].x, v.y + rv[it].y, v.z + rv[it].z, v.w + rv[it].w);
+        for (int mb = 0; mb < MP; ++mb) {
+            const int mi = ps * MP + mb, r = mb * 16 + fr;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int ch = 2 * (q * 4 + fq);
+                *(float4*)(stage + r * 256 + ((ch ^ (r & 15)) << 4)) =
+                    make_float4(acc[2 * q][mi][0] + bb[q][0], acc[2 * q][mi][1] + bb[q][1], acc[2 * q][mi][2] + bb[q][2], acc[2 * q][mi][3] + bb[q][3]);
+                *(float4*)(stage + r * 256 + (((ch + 1) ^ (r & 15)) << 4)) =
+                    make_float4(acc[2 * q + 1][mi][0] + bb[q][4], acc[2 * q + 1][mi][1] + bb[q][5], acc[2 * q + 1][mi][2] + bb[q][6], acc[2 * q + 1][mi][3] + bb[q][7]);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < MP * 4; ++it) {
+            const int row = it * 4 + rr, m = mw0 + ps * MP * 16 + row;
+            const float4 v = *(const float4*)(stage + row * 256 + ((c ^ (row & 15)) << 4));
+            if (m < p.M && n < p.N)
+                *(float4*)((float*)p.out_f + (long)m * p.o_sW + p.o_c0 + zo + n) = make_float4(v.x + rv[it].x, v.y + rv[it].y, v.z + rv[it].z, v.w + rv[it].w);
+        }
+        if constexpr (PASSES > 1) {                        // the next pass overwrites the stage: its reads must have completed
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
     }
 }
 
@@ -484,9 +493,8 @@ __device__ __forceinline__ void gemm_epilogue_plain(const advh_gemm_desc& p, f32
     if constexpr (NI == 4) {
         if (stage && mode == 0) return gemm_epilogue_staged<MI, NI, SPLIT, 0>(p, acc, stage, mw0, nw0, fr + 16 * fq, z, zo);
         if (stage && mode == 1) return gemm_epilogue_staged<MI, NI, SPLIT, 1>(p, acc, stage, mw0, nw0, fr + 16 * fq, z, zo);
-        if constexpr (SPLIT) {                              // the fp32-class kernels' stage holds the wavefront's tile as fp32 too
-            if (stage && mode == 2) return gemm_epilogue_staged_f32<MI, NI>(p, acc, stage, mw0, nw0, fr + 16 * fq, z, zo);
-        }
+        // the fp32-class kernels' stage holds the wavefront's whole tile as fp32, the fp16 kernels stage it in four passes
+        if (stage && mode == 2) return gemm_epilogue_staged_f32<MI, NI, SPLIT ? 1 : 4>(p, acc, stage, mw0, nw0, fr + 16 * fq, z, zo);
     }
     if (mode == 0) gemm_epilogue_tight<MI, NI, SPLIT, 0, PRE>(p, acc, mw0, nw0, fr, fq, z, zo);
     else if (mode == 1) gemm_epilogue_tight<MI, NI, SPLIT, 1, PRE>(p, acc, mw0, nw0, fr, fq, z, zo);
