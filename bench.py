@@ -40,6 +40,8 @@ sys.path.insert(0, ROOT)
 
 BATCH = 64
 AUDIO_LENGTH = 4
+DATASET_CLIPS = 71237                       # BASELINE config 4: the ASVspoof2019-LA evaluation partition's size
+DATASET_SHARE = -(-DATASET_CLIPS // 8)      # one of eight ranks' contiguous block (8 905 clips, last batch 9)
 MFMA_F16_PEAK_TFLOPS = 2500.0        # MI355X dense fp16/bf16 MFMA peak (MI355X_MICROARCH.md)
 PEAK = {"f16": MFMA_F16_PEAK_TFLOPS, "f32": MFMA_F16_PEAK_TFLOPS / 3.0}     # fp32-class: 3 fp16 MFMAs per product
 PEAK_NOTE = {"f16": "dense fp16 MFMA peak", "f32": "dense fp16 MFMA peak / 3: the fp32-class mode issues three fp16 MFMAs per product "
@@ -337,7 +339,7 @@ def explain_line(ctx):
 
 
 # ------------------------------------------------------------------------------------------ BASELINE config 4 (one GPU's loop)
-def bench_dataset(ctx, precision, n_clips=4133, pool=512):
+def bench_dataset(ctx, precision, n_clips=DATASET_SHARE, pool=512):
     """The dataset loop of LMAC_metrics.run_addvisor_metrics (LMAC_metrics.py:117-172) as one rank of config 4 runs it:
     clips live in HOST memory (pinned), every batch of 64 is uploaded over PCIe on a copy stream while the previous batch
     computes (two device buffers), the last batch is ragged (n_clips % 64 != 0), the per-clip probabilities are gathered and
@@ -382,7 +384,8 @@ def bench_dataset(ctx, precision, n_clips=4133, pool=512):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     n_local = idx.stop - idx.start
-    out = {"workload": f"BASELINE config 4 as one rank runs it: {n_local} clips x 4 s from pinned host memory in batches of {B} (last batch {n_local % B or B}), "
+    out = {"workload": f"BASELINE config 4 as one rank runs it: {n_local} clips x 4 s (one of eight ranks' share of an ASVspoof2019-LA-sized set of {DATASET_CLIPS}) "
+                       f"from pinned host memory in batches of {B} (last batch {n_local % B or B}), "
                        "upload overlapped on a copy stream, LMAC metrics at the end; wav2vec2-base + U-Net",
            "value": round(n_local / dt, 1), "unit": "explanations/s (PCIe upload included)", "seconds": round(dt, 3), "clips": n_local, "dtype": precision,
            "upload_GB": round(n_local * L * 4 / 1e9, 3), "lmac": {k: round(v, 6) for k, v in metrics.items()}}
