@@ -8,7 +8,7 @@ import torch
 from addvisor_hip import _lib, gemm as G
 _lib.init()
 dev = torch.device("cuda:0")
-M, K, N = 38208, 768, 2304
+M, K, N = (int(v) for v in sys.argv[1:4]) if len(sys.argv) > 3 else (38208, 768, 2304)
 g = torch.Generator().manual_seed(0)
 w = torch.randn(N, K, generator=g) / K ** 0.5
 a = torch.randn(M + 1024, K, generator=g)
@@ -28,8 +28,8 @@ st = (ctypes.c_longlong * 8)()
 assert fn(st) == 0
 s = list(st)
 cyc, ticks = s[2] - s[0], s[3] - s[1]
-print(f"x3 128x128 QKV shape after {n} launches: one workgroup's K loop = {cyc} core cycles in {ticks} x 10 ns -> clock {cyc / ticks * 100:.0f} MHz; "
-      f"12 K-steps -> {cyc / 12:.0f} cycles per K-step (96 MFMAs = 1 536 cycles of MFMA issue per wavefront)")
+print(f"x3 128x128 M={M} K={K} N={N} after {n} launches: one workgroup's K loop = {cyc} core cycles in {ticks} x 10 ns -> clock {cyc / ticks * 100:.0f} MHz; "
+      f"{K // 64} K-steps -> {cyc / (K // 64):.0f} cycles per K-step (96 MFMAs = 1 536 cycles of MFMA issue per wavefront)")
 print(f"whole workgroup {s[5] - s[4]} cycles: prologue {s[0] - s[4]}, K loop {cyc}, fold + epilogue (to the last store retired) {s[5] - s[2]}")
 print(f"  fold {s[6] - s[2]}, epilogue issue {s[7] - s[6]}, wait for the stores {s[5] - s[7]}")
 fk = _lib.lib().advh_debug_kstep

@@ -157,9 +157,9 @@ def super_columns(N: int, Kp: int, M: int, bn: int = 128, split: bool = False) -
     if tiles_n * bn * Kp * bpe <= 3 * 1024 * 1024:
         return 0
     sc = min(tiles_n, budget // (bn * Kp * bpe))
-    if split:
-        return max(1, sc)
-    return sc if sc >= 4 else 0            # narrower super-columns re-read the activations too often (deep-K layers)
+    # narrower super-columns re-read the activations too often (deep-K layers): FFN2 in the fp32-class mode (K = 3072, six
+    # column tiles of 1.5 MB) ran 301 / 323 / 359 / 362 TFLOP/s with super-columns of 1 / 2 / 3 / all tiles (warm clock)
+    return sc if sc >= (3 if split else 4) else 0
 
 
 PLAIN_ROWS = os.environ.get("ADDVISOR_GEMM_PLAIN", "1") != "0"          # A/B switch for the affine-row loader
