@@ -924,6 +924,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_x3_kernel(const advh_gem
 #ifdef ADVH_STAMPS
         if (stamp_here) g_kstep[3] = __builtin_amdgcn_s_memtime();     // barrier passed
 #endif
+        __builtin_amdgcn_s_setprio(1);     // the MFMA phase wins issue arbitration over the co-resident workgroup's DMA issue: +1-2 % (warm clock)
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             f16x8 bh[NI], bl[NI];
@@ -944,6 +945,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_x3_kernel(const advh_gem
                 for (int ni = 0; ni < NI; ++ni) accx[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[ni], ah, accx[ni][mi], 0, 0, 0);
             }
         }
+        __builtin_amdgcn_s_setprio(0);
 #ifdef ADVH_STAMPS
         if (stamp_here) g_kstep[4] = __builtin_amdgcn_s_memtime();     // MFMAs issued
 #endif
