@@ -92,3 +92,48 @@ def test_conv_forms_match_generic(gpu_device, monkeypatch, split, Cin, Cout, act
         outs.append(dst.t.clone())
     monkeypatch.undo()
     assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("split", [False, True])
+@pytest.mark.parametrize("with_resid,with_h2,inplace", [(True, True, False), (True, False, True), (False, True, False)])
+def test_resblock_forms_match_generic(gpu_device, monkeypatch, split, with_resid, with_h2, inplace):
+    """bias, no activation, fp16-side residual and / or the leaky copy (the second convolution of a HiFi-GAN ResBlock step,
+    `x = x + conv2(...)`; `inplace`: the output IS the residual buffer): the fp32-staged form against the generic epilogue."""
+    _lib.init()
+    B, H, W, Cin, Cout = 2, 9, 150, 64, 128
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(B, H, W, Cin, generator=g)
+    r = torch.randn(B, H, W, Cout, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (9 * Cin) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    src = G.FMap(B, H, W, Cin, 1, 1, split=split).alloc(gpu_device)
+    res = G.FMap(B, H, W, Cout, 1, 1, split=split).alloc(gpu_device)
+    if split:
+        src.t[:, :, 1:1 + H, 1:1 + W] = G.split_planes(x).to(gpu_device)
+        res.t[:, :, 1:1 + H, 1:1 + W] = G.split_planes(r).to(gpu_device)
+    else:
+        src.interior()[:] = x.half().to(gpu_device)
+        res.interior()[:] = r.half().to(gpu_device)
+    outs = []
+    for wide_on in (True, False):
+        if not wide_on:
+            monkeypatch.setattr(G, "WIDE_EPILOGUE", False)
+        dst = G.FMap(B, H, W, Cout, 1, 1, split=split).alloc(gpu_device)
+        dst2 = G.FMap(B, H, W, Cout, 1, 1, split=split).alloc(gpu_device)
+        dst.t.fill_(5.0)
+        dst2.t.fill_(6.0)
+        rbuf = res.t.clone()
+        out = rbuf if inplace else dst.t
+        p = G.plan_conv2d([src], dst, w, b, act="none", device=gpu_device)
+        p.desc.slope2 = 0.1
+        assert p.desc.wide == int(wide_on)
+        p.run(src.t, out_h=out, resid=rbuf if with_resid else None, out_h2=dst2.t if with_h2 else None)
+        outs.append((out.clone(), dst2.t.clone()))
+    monkeypatch.undo()
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    ref = torch.nn.functional.conv2d((x.half().float() if not split else x).permute(0, 3, 1, 2), w.half().float() if not split else w, b, padding=1).permute(0, 2, 3, 1)
+    if with_resid:
+        ref = ref + (r.half().float() if not split else r)
+    got = outs[0][0]
+    got = (G.join_planes(got) if split else got.float())[:, 1:1 + H, 1:1 + W].cpu()
+    assert (got - ref).abs().max().item() <= (3e-6 if split else 6e-3) * ref.abs().max().item()

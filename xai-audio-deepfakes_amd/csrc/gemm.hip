@@ -506,6 +506,92 @@ template <int MI, int NI, bool SPLIT = false>
 __device__ __forceinline__ void gemm_epilogue(const advh_gemm_desc& p, f32x4 (&acc)[NI][MI], int mw0, int nw0, int fr, int fq, int z,
                                               long zo = -1);            // zo: output offset of batch z (default o_sZ * z)
 
+// Staged form for the second convolution of a HiFi-GAN ResBlock step (hifigan.py:180 -> Kong et al. ResBlock1: x = x + conv2(...)):
+// bias, no activation, optional fp16-side residual (same layout as the output), fp16-side output and optionally its leaky copy
+// (out_h2, the next convolution's input).  The tile goes through LDS as fp32 -- the residual is added to the unrounded value,
+// exactly as in the generic form -- in PASSES passes of 16 MI / PASSES rows (fp32-class kernels: one pass; fp16 kernels: four, which keeps them at 128 VGPRs);
+// the residual of a pass is prefetched in the store layout before its first store (out_h may be resid), 16 lanes x 8 bytes = one
+// full 128-byte line per row and plane, 4 rows per instruction.
+template <int MI, int NI, bool SPLIT, int PASSES>
+__device__ __forceinline__ void gemm_epilogue_rows_staged_resid(const advh_gemm_desc& p, f32x4 (&acc)[NI][MI], char* stage, int mw0, int nw0,
+                                                                int lane, int z, long zo) {
+    static_assert(NI == 4 && MI % PASSES == 0, "64-column wavefront tile");
+    constexpr int MP = MI / PASSES;
+    typedef _Float16 f16x4v __attribute__((ext_vector_type(4)));
+    const int fr = lane & 15, fq = lane >> 4;
+    const int rr = lane >> 4, c = lane & 15, n = nw0 + c * 4;
+    unsigned Wg = p.Wg, Hg = p.Hg;
+    asm volatile("" : "+s"(Wg), "+s"(Hg));
+    const RowDecomp rd(Wg, Hg);
+    const bool has_r = p.resid != nullptr;
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps) {
+        long ofs[MP * 4];                                   // output element offset of this lane's 4 channels per row; -1: row not written
+        bool okr[MP * 4];
+        f16x4v rh[MP * 4], rl[MP * 4];
+#pragma unroll
+        for (int it = 0; it < MP * 4; ++it) {
+            const int m = mw0 + ps * MP * 16 + it * 4 + rr;
+            ofs[it] = -1;
+            okr[it] = false;
+            rh[it] = f16x4v{(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+            rl[it] = rh[it];
+            if (m < p.M && n < p.N) {
+                unsigned w, h, b;
+                rd((unsigned)m, b, h, w);
+                const bool ok = (int)h >= p.h0 && (int)h < p.h1 && (int)w >= p.w0 && (int)w < p.w1;
+                if (ok || p.halo_zero) {
+                    ofs[it] = (long)b * p.o_sB + (long)h * p.o_sH + (long)w * p.o_sW + p.o_c0 + zo + n;
+                    okr[it] = ok;
+                    if (ok && has_r) {
+                        rh[it] = *(const f16x4v*)((const _Float16*)p.resid + ofs[it]);
+                        if constexpr (SPLIT) rl[it] = *(const f16x4v*)((const _Float16*)p.resid + ofs[it] + p.o_lo);
+                    }
+                }
+            }
+        }
+        float bb[2][8];
+        load_bias8<2>(p, z, nw0 + fq * 8, bb);
+#pragma unroll
+        for (int mb = 0; mb < MP; ++mb) {
+            const int mi = ps * MP + mb, r = mb * 16 + fr;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int ch = 2 * (q * 4 + fq);
+                *(float4*)(stage + r * 256 + ((ch ^ (r & 15)) << 4)) =
+                    make_float4(acc[2 * q][mi][0] + bb[q][0], acc[2 * q][mi][1] + bb[q][1], acc[2 * q][mi][2] + bb[q][2], acc[2 * q][mi][3] + bb[q][3]);
+                *(float4*)(stage + r * 256 + (((ch + 1) ^ (r & 15)) << 4)) =
+                    make_float4(acc[2 * q + 1][mi][0] + bb[q][4], acc[2 * q + 1][mi][1] + bb[q][5], acc[2 * q + 1][mi][2] + bb[q][6], acc[2 * q + 1][mi][3] + bb[q][7]);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < MP * 4; ++it) {
+            const int row = it * 4 + rr;
+            const float4 t = *(const float4*)(stage + row * 256 + ((c ^ (row & 15)) << 4));
+            if (ofs[it] < 0) continue;
+            float v[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (!okr[it]) v[k] = 0.f;
+                else if (has_r) v[k] += SPLIT ? join_f32(rh[it][k], rl[it][k]) : (float)rh[it][k];
+            }
+            store_h<4, SPLIT>(p.out_h, ofs[it], p.o_lo, v);
+            if (p.out_h2) {
+                float w2[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) w2[k] = v[k] > 0.f ? v[k] : p.slope2 * v[k];
+                store_h<4, SPLIT>(p.out_h2, ofs[it], p.o_lo, w2);
+            }
+        }
+        if constexpr (PASSES > 1) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
 // the row-decomposing epilogue of the two single-buffered kernels: staged / tight form where the descriptor allows, else general
 template <int MI, int NI, bool SPLIT>
 __device__ __forceinline__ void gemm_epilogue_rows(const advh_gemm_desc& p, f32x4 (&acc)[NI][MI], char* stage, int mw0, int nw0, int fr, int fq,
@@ -522,6 +608,11 @@ __device__ __forceinline__ void gemm_epilogue_rows(const advh_gemm_desc& p, f32x
         if (p.act == ADVH_ACT_LEAKY) return gemm_epilogue_rows_tight<MI, NI, SPLIT, ADVH_ACT_LEAKY>(p, acc, mw0, nw0, fr, fq, z, zo);
         if (p.act == ADVH_ACT_GELU) return gemm_epilogue_rows_tight<MI, NI, SPLIT, ADVH_ACT_GELU>(p, acc, mw0, nw0, fr, fq, z, zo);
         return gemm_epilogue_rows_tight<MI, NI, SPLIT, ADVH_ACT_NONE>(p, acc, mw0, nw0, fr, fq, z, zo);
+    }
+    if constexpr (NI == 4) {
+        const bool resid_form = stage && p.wide && p.n_div >= p.N && p.ph_r <= 0 && p.out_h && !p.out_f && !p.out_pre && !p.dact_src &&
+                                p.act == ADVH_ACT_NONE && (p.out_h2 || (p.resid && !p.resid_f32)) && !(p.resid && p.resid_f32);
+        if (resid_form) return gemm_epilogue_rows_staged_resid<MI, NI, SPLIT, SPLIT ? 1 : 4>(p, acc, stage, mw0, nw0, fr + 16 * fq, z, zo);
     }
     gemm_epilogue<MI, NI, SPLIT>(p, acc, mw0, nw0, fr, fq, z, zo);
 }
