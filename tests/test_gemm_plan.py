@@ -248,3 +248,17 @@ def test_split_format_roundtrip():
     assert (r - x).abs()[~big].max().item() <= 2.0 ** -25
     assert (t[0][~big] == 0).all()                       # no fp16 subnormal ever reaches the matrix cores through hi
     assert torch.equal(G.join_planes(t), r.float())
+
+
+def test_super_column_rule():
+    """Tile order of the Linear layers (gemm.super_columns): a super-column keeps `sc` weight-column tiles L2-resident while all
+    row tiles pass; it is switched off when fewer than 4 (fp16) / 3 (fp32-class) column tiles fit the 1.6 MB budget, because the
+    activations are then re-read too often (FFN2, K = 3072: 301 TFLOP/s at sc = 1, 362 with super-columns off)."""
+    M = 38208
+    assert G.super_columns(768, 768, M) == 0                          # whole weight under 3 MB: resident anyway
+    assert G.super_columns(2304, 768, M) == 8                         # QKV fp16: 128 x 768 x 2 B = 196 608 B per column tile
+    assert G.super_columns(2304, 768, M, split=True) == 4             # same in the split format (4 B per element)
+    assert G.super_columns(3072, 768, M, split=True) == 4             # FFN1
+    assert G.super_columns(768, 3072, M, split=True) == 0             # FFN2: 1.5 MB per column tile -> off
+    assert G.super_columns(768, 3072, M) == 0                         # fp16: two tiles fit, fewer than four -> off
+    assert G.super_columns(64, 4608, M, split=True) == 0              # a single column tile
