@@ -381,6 +381,26 @@ int advh_unet_pack_x_split(const float* mag, int Fq, int Tq, int B, int H, int W
                            int PH, int PW, advh_stream_t stream);
 int advh_unet_head_split(const void* y, int64_t y_lo, int B, int H, int W, int PH, int PW, const float* wgt, float bias,
                          float* mask, float* logits, advh_stream_t stream);
+/* fp32-class input-gradient chain (captum_saliency.py:116-135: fp32 autograd through the embedder; loss_function.py:46-53 +
+ * train_addvisor.py:376: loss.backward() through the frozen embedder).  Dense dgrad products are advh_gemm_f16 launches with
+ * desc.split = 1 (transposed split weights, split gradients; dact_src / out_pre are plane pairs sharing o_lo); these are the
+ * split-format forms of the row kernels above -- same arithmetic, fp16 tensors replaced by plane pairs -- and the attention
+ * backward on the fp32-input matrix instruction (v_mfma_f32_16x16x4_f32; head dim a multiple of 8 up to 128, T <= 256).  */
+int advh_layernorm_bwd_split(const void* x, int x_is_f32, int64_t x_lo, const void* dy, int dy_is_f32, int64_t dy_lo,
+                             const float* gamma, const float* beta, int gelu_fwd, const float* add, const void* dact_src,
+                             int64_t dact_lo, float* out_f, void* out_h, int64_t out_lo, int M, int C, float eps, int remap_T,
+                             int remap_P, advh_stream_t stream);
+int advh_attention_bwd_split(const void* qkv, int64_t qkv_lo, const void* dctx, int64_t dctx_lo, void* dqkv, int64_t dqkv_lo,
+                             int B, int T, int H, int heads, advh_stream_t stream);
+int advh_pool_logreg_bwd_split(const float* coef, const float* dlogit, float* dh, void* dh16, int64_t dh16_lo, int B, int T, int H,
+                               advh_stream_t stream);
+/* dh [B][T][H] fp32 times GELU'(dact_src) (split pre-activation of the positional conv) -> split xg, rows [pad_left, pad_left+T) */
+int advh_posconv_gather_bwd_split(const float* dh, void* xg, int64_t xg_lo, int B, int T, int H, int G, int K, int pad_left,
+                                  const void* dact_src, int64_t dact_lo, advh_stream_t stream);
+int advh_w2v2_frontend_bwd_group_split(const float* wave, int64_t wave_stride, int n_in, int B, int L, const float* w0,
+                                       const float* gamma, const float* stats_ws, const float* norm_ws, const float* mr_ws,
+                                       const void* dy0, int64_t dy_lo, float* part_ws, float* sums_ws, void* dz0, int64_t dz_lo,
+                                       int T0, int P0, int C0, advh_stream_t stream);
 /* HiFi-GAN generator pieces on split-format maps [2][B][T+2*halo][C] (the Conv1d / ConvTranspose1d layers are advh_gemm_f16
  * launches with desc.split = 1; advh_halo_fill_f16 serves both planes when called with 2*B maps).  `pad` = inference padding. */
 int advh_hifigan_pack_mel_split(const float* mel, void* out, int64_t out_lo, int B, int C, int T, int pad, int halo,

@@ -29,8 +29,11 @@ def gauss_legendre(n_steps: int) -> Tuple[np.ndarray, np.ndarray]:
 
 
 class HipAttribution:
-    def __init__(self, emb: HipEmbedder, loss_scale: float = 4096.0):
-        self.emb, self.eg, self.loss_scale = emb, EmbedderGrad(emb), loss_scale
+    def __init__(self, emb: HipEmbedder, loss_scale: float = 4096.0, precision: Optional[str] = None):
+        """``precision``: None = the embedder's (an fp32-class embedder gives the fp32-class gradient chain, the reference's
+        fp32 autograd class); "f16" = the fp16-operand chain."""
+        self.emb, self.eg, self.loss_scale = emb, EmbedderGrad(emb, precision), loss_scale
+        self.precision = self.eg.precision
 
     def _prep(self, waves: torch.Tensor) -> torch.Tensor:
         if waves.dim() == 1:
@@ -46,6 +49,12 @@ class HipAttribution:
     def _finalize(self, g, x, mode):
         out = torch.empty_like(g)
         _lib.check(_lib.lib().advh_attr_finalize(g.data_ptr(), x.data_ptr(), out.data_ptr(), mode, g.numel(), _st()), "advh_attr_finalize")
+        # the planes between the dgrad GEMMs have fp16's exponent range: an overflow (|scaled gradient| > 65504 somewhere in the
+        # chain) surfaces as inf / NaN in the input gradient and in every sum over path points.  One flag read per attribution:
+        # raise instead of handing back a poisoned attribution map.
+        if not bool(torch.isfinite(out).all()):
+            raise FloatingPointError(f"non-finite attribution: the gradient chain overflowed at loss_scale={self.loss_scale:g} "
+                                     "(lower HipAttribution.loss_scale by a power of two)")
         return out
 
     def saliency(self, waves):

@@ -321,12 +321,11 @@ class GemmPlan:
                 if t is not None:
                     assert t.shape[0] == 2 and t.stride(0) % 8 == 0, "split operand must be a [2, ...] plane pair"
                     d.a_lo[s_] = t.stride(0) // 8
-            for t in (out_h, out_h2, resid if (resid is not None and resid.dtype == torch.float16) else None):
+            for t in (out_h, out_h2, out_pre, dact_src, resid if (resid is not None and resid.dtype == torch.float16) else None):
                 if t is not None:
                     assert t.shape[0] == 2 and t.stride(0) % 8 == 0 and o_lo in (None, t.stride(0)), "split outputs share one plane pitch"
                     o_lo = t.stride(0)
             d.o_lo = o_lo or 0
-            assert out_pre is None and dact_src is None
         d.A0 = A0.data_ptr()
         d.A1 = A1.data_ptr() if A1 is not None else None
         assert (A1 is not None) == (self.nsrc == 2)

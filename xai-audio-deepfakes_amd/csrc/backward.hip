@@ -25,15 +25,14 @@ __device__ __forceinline__ float wsum(float v) {
     return v;
 }
 
+// fp32 row, fp16 row (lo == 0) or a split-format plane pair (lo = distance to the lo plane, device_math.h)
 template <bool F32>
-__device__ __forceinline__ void load4(const void* p, long off, float (&v)[4]) {
+__device__ __forceinline__ void load4(const void* p, long off, float (&v)[4], long lo = 0) {
     if (F32) {
         float4 t = *(const float4*)((const float*)p + off);
         v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
     } else {
-        f16x4 t = *(const f16x4*)((const _Float16*)p + off);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = (float)t[r];
+        load_h_rt<4>((const _Float16*)p, off, lo, v);
     }
 }
 
@@ -47,7 +46,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
                                                             int gelu_fwd, const float* __restrict__ add,
                                                             const _Float16* __restrict__ dact_src, float* __restrict__ out_f,
                                                             _Float16* __restrict__ out_h, int M, int C, float eps,
-                                                            int remap_T, int remap_P) {
+                                                            int remap_T, int remap_P, long x_lo, long dy_lo, long dact_lo, long out_lo) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -59,7 +58,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
     for (int i = 0; i < MAXV; ++i) {
         int c = (i * 64 + lane) * 4;
         if (c < C) {
-            load4<X32>(x, row * C + c, xv[i]);
+            load4<X32>(x, row * C + c, xv[i], x_lo);
             s += (xv[i][0] + xv[i][1]) + (xv[i][2] + xv[i][3]);
         } else {
 #pragma unroll
@@ -83,7 +82,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
         int c = (i * 64 + lane) * 4;
         if (c < C) {
             float d[4];
-            load4<DY32>(dy, row * C + c, d);
+            load4<DY32>(dy, row * C + c, d, dy_lo);
             float4 g = *(const float4*)(gamma + c);
             float gm[4] = {g.x, g.y, g.z, g.w};
             float bt[4] = {0.f, 0.f, 0.f, 0.f};
@@ -110,19 +109,17 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
 #pragma unroll
             for (int r = 0; r < 4; ++r) o[r] = rstd * (gv[i][r] - mg - xv[i][r] * mgx);
             if (dact_src) {
-                f16x4 z = *(const f16x4*)(dact_src + row * C + c);
+                float z[4];
+                load_h_rt<4>(dact_src, row * C + c, dact_lo, z);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] *= gelu_grad((float)z[r]);
+                for (int r = 0; r < 4; ++r) o[r] *= gelu_grad(z[r]);
             }
             if (add) {
                 float4 a = *(const float4*)(add + row * C + c);
                 o[0] += a.x; o[1] += a.y; o[2] += a.z; o[3] += a.w;
             }
             if (out_f) *(float4*)(out_f + orow * C + c) = make_float4(o[0], o[1], o[2], o[3]);
-            if (out_h) {
-                f16x4 h = {(_Float16)o[0], (_Float16)o[1], (_Float16)o[2], (_Float16)o[3]};
-                *(f16x4*)(out_h + orow * C + c) = h;
-            }
+            if (out_h) store_h_rt<4>(out_h, orow * C + c, out_lo, o);
         }
     }
 }
@@ -408,7 +405,7 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const _Float16* __re
 // ---------------------------------------------------------------------------------------------- head / misc
 // dh[b][t][:] = coef[:] * (dlogit[b] / T)      (gradient of mean-pool + Linear(H,1))
 __global__ __launch_bounds__(256) void pool_logreg_bwd_kernel(const float* __restrict__ coef, const float* __restrict__ dlogit,
-                                                              float* __restrict__ dh, _Float16* __restrict__ dh16, int T, int H, long total4) {
+                                                              float* __restrict__ dh, _Float16* __restrict__ dh16, int T, int H, long total4, long dh16_lo) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
         int c = (int)(i % (H / 4)) * 4;
         long bt = i / (H / 4);
@@ -417,10 +414,7 @@ __global__ __launch_bounds__(256) void pool_logreg_bwd_kernel(const float* __res
         float4 w = *(const float4*)(coef + c);
         float o[4] = {w.x * s, w.y * s, w.z * s, w.w * s};
         if (dh) *(float4*)(dh + bt * H + c) = make_float4(o[0], o[1], o[2], o[3]);
-        if (dh16) {
-            f16x4 h = {(_Float16)o[0], (_Float16)o[1], (_Float16)o[2], (_Float16)o[3]};
-            *(f16x4*)(dh16 + bt * H + c) = h;
-        }
+        if (dh16) store_h_rt<4>(dh16, bt * H + c, dh16_lo, o);
     }
 }
 
@@ -492,9 +486,10 @@ extern "C" int advh_time_mask(const float* attr, float* mask, float* wave_in, fl
     return ADVH_LAUNCH_CHECK();
 }
 
-extern "C" int advh_layernorm_bwd(const void* x, int x_is_f32, const void* dy, int dy_is_f32, const float* gamma,
-                                  const float* beta, int gelu_fwd, const float* add, const void* dact_src, float* out_f,
-                                  void* out_h, int M, int C, float eps, int remap_T, int remap_P, advh_stream_t stream) {
+static int layernorm_bwd_launch(const void* x, int x_is_f32, const void* dy, int dy_is_f32, const float* gamma,
+                                const float* beta, int gelu_fwd, const float* add, const void* dact_src, float* out_f,
+                                void* out_h, int M, int C, float eps, int remap_T, int remap_P, long x_lo, long dy_lo, long dact_lo,
+                                long out_lo, advh_stream_t stream) {
     if (remap_P > 0 && (remap_T <= 0 || remap_P < remap_T)) return ADVH_EINVAL;
     if (!x || !dy || !gamma || (gelu_fwd && !beta) || (!out_f && !out_h) || M <= 0 || C <= 0 || C % 4) return ADVH_EINVAL;
     if (C > 64 * 4 * 8) return ADVH_EUNSUPPORTED;
@@ -502,7 +497,7 @@ extern "C" int advh_layernorm_bwd(const void* x, int x_is_f32, const void* dy, i
     hipStream_t s = (hipStream_t)stream;
 #define LNB(X32, D32, MV)                                                                                            \
     hipLaunchKernelGGL((layernorm_bwd_kernel<X32, D32, MV>), grid, block, 0, s, x, dy, gamma, beta, gelu_fwd, add,     \
-                       (const _Float16*)dact_src, out_f, (_Float16*)out_h, M, C, eps, remap_T, remap_P)
+                       (const _Float16*)dact_src, out_f, (_Float16*)out_h, M, C, eps, remap_T, remap_P, x_lo, dy_lo, dact_lo, out_lo)
 #define LNB_MV(MV)                                                                                                   \
     do {                                                                                                             \
         if (x_is_f32 && dy_is_f32) LNB(true, true, MV); else if (x_is_f32) LNB(true, false, MV);                     \
@@ -512,6 +507,23 @@ extern "C" int advh_layernorm_bwd(const void* x, int x_is_f32, const void* dy, i
 #undef LNB_MV
 #undef LNB
     return ADVH_LAUNCH_CHECK();
+}
+
+extern "C" int advh_layernorm_bwd(const void* x, int x_is_f32, const void* dy, int dy_is_f32, const float* gamma,
+                                  const float* beta, int gelu_fwd, const float* add, const void* dact_src, float* out_f,
+                                  void* out_h, int M, int C, float eps, int remap_T, int remap_P, advh_stream_t stream) {
+    return layernorm_bwd_launch(x, x_is_f32, dy, dy_is_f32, gamma, beta, gelu_fwd, add, dact_src, out_f, out_h, M, C, eps, remap_T,
+                                remap_P, 0, 0, 0, 0, stream);
+}
+
+extern "C" int advh_layernorm_bwd_split(const void* x, int x_is_f32, int64_t x_lo, const void* dy, int dy_is_f32, int64_t dy_lo,
+                                        const float* gamma, const float* beta, int gelu_fwd, const float* add, const void* dact_src,
+                                        int64_t dact_lo, float* out_f, void* out_h, int64_t out_lo, int M, int C, float eps,
+                                        int remap_T, int remap_P, advh_stream_t stream) {
+    if ((!x_is_f32 && x_lo <= 0) || (!dy_is_f32 && dy_lo <= 0) || (dact_src && dact_lo <= 0) || (out_h && out_lo <= 0)) return ADVH_EINVAL;
+    if (x_lo % 4 || dy_lo % 4 || dact_lo % 4 || out_lo % 4) return ADVH_EINVAL;
+    return layernorm_bwd_launch(x, x_is_f32, dy, dy_is_f32, gamma, beta, gelu_fwd, add, dact_src, out_f, out_h, M, C, eps, remap_T,
+                                remap_P, x_is_f32 ? 0 : x_lo, dy_is_f32 ? 0 : dy_lo, dact_src ? dact_lo : 0, out_h ? out_lo : 0, stream);
 }
 
 template <int NT, int D, bool TR>
@@ -545,15 +557,26 @@ extern "C" int advh_attention_bwd_f16(const void* qkv, const void* dctx, void* d
 #undef ATBT
 }
 
-extern "C" int advh_pool_logreg_bwd(const float* coef, const float* dlogit, float* dh, void* dh16, int B, int T, int H,
-                                    advh_stream_t stream) {
+static int pool_logreg_bwd_launch(const float* coef, const float* dlogit, float* dh, void* dh16, long dh16_lo, int B, int T, int H,
+                                  advh_stream_t stream) {
     if (!coef || !dlogit || (!dh && !dh16) || B <= 0 || T <= 0 || H <= 0 || H % 4) return ADVH_EINVAL;
     long total4 = (long)B * T * (H / 4);
     long blocks = (total4 + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(pool_logreg_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, coef, dlogit, dh,
-                       (_Float16*)dh16, T, H, total4);
+                       (_Float16*)dh16, T, H, total4, dh16_lo);
     return ADVH_LAUNCH_CHECK();
+}
+
+extern "C" int advh_pool_logreg_bwd(const float* coef, const float* dlogit, float* dh, void* dh16, int B, int T, int H,
+                                    advh_stream_t stream) {
+    return pool_logreg_bwd_launch(coef, dlogit, dh, dh16, 0, B, T, H, stream);
+}
+
+extern "C" int advh_pool_logreg_bwd_split(const float* coef, const float* dlogit, float* dh, void* dh16, int64_t dh16_lo, int B, int T,
+                                          int H, advh_stream_t stream) {
+    if (dh16 && (dh16_lo <= 0 || dh16_lo % 4)) return ADVH_EINVAL;
+    return pool_logreg_bwd_launch(coef, dlogit, dh, dh16, dh16 ? dh16_lo : 0, B, T, H, stream);
 }
 
 extern "C" int advh_scale_rows(const float* x, int x_rows, const float* alpha, float* y, int rows, int64_t n, int accumulate,

@@ -30,7 +30,7 @@ __global__ __launch_bounds__(256) void gn0_bwd_kernel(const float* __restrict__ 
                                                       const float2* __restrict__ norm, const float2* __restrict__ mr,
                                                       const float* __restrict__ gamma, const _Float16* __restrict__ dy,
                                                       float2* __restrict__ part, const float2* __restrict__ sums,
-                                                      _Float16* __restrict__ dz, int T0, int P0, int C0) {
+                                                      _Float16* __restrict__ dz, int T0, int P0, int C0, long dy_lo, long dz_lo) {
     __shared__ float xs[TT * S0 + K0];
     const int b = blockIdx.y, t0 = blockIdx.x * TT, tid = threadIdx.x, ntile = gridDim.x;
     const float* w = wave + (long)b * stride;
@@ -60,14 +60,15 @@ __global__ __launch_bounds__(256) void gn0_bwd_kernel(const float* __restrict__ 
             float za = 0.f, zb = 0.f;
 #pragma unroll
             for (int k = 0; k < K0; ++k) { float x = xs[S0 * t + k]; za = fmaf(wa[k], x, za); zb = fmaf(wb[k], x, zb); }
-            __half2 d2 = *(const __half2*)(dy + o);
-            float dna = __low2float(d2) * gelu_grad(za * na.x + na.y) * ga;
-            float dnb = __high2float(d2) * gelu_grad(zb * nb.x + nb.y) * gb;
+            float d2[2];
+            load_h_rt<2>(dy, o, dy_lo, d2);                   // fp16, or the split-format plane pair (dy_lo != 0)
+            float dna = d2[0] * gelu_grad(za * na.x + na.y) * ga;
+            float dnb = d2[1] * gelu_grad(zb * nb.x + nb.y) * gb;
             float ha = (za - ma.x) * ma.y, hb = (zb - mb.x) * mb.y;
             if (PASS == 0) { s1a += dna; s2a += dna * ha; s1b += dnb; s2b += dnb * hb; }
             else { da = ma.y * (dna - m1a - ha * m2a); db = mb.y * (dnb - m1b - hb * m2b); }
         }
-        if (PASS == 1) *(__half2*)(dz + o) = __floats2half2_rn(da, db);
+        if (PASS == 1) { const float dd[2] = {da, db}; store_h_rt<2>(dz, o, dz_lo, dd); }
     }
     if (PASS == 0) {
         part[((long)b * ntile + blockIdx.x) * C0 + c] = make_float2(s1a, s2a);
@@ -152,22 +153,39 @@ __global__ __launch_bounds__(256) void wave_bwd_final_kernel(const float* __rest
 
 using namespace advh;
 
-extern "C" int advh_w2v2_frontend_bwd_group(const float* wave, int64_t wave_stride, int n_in, int B, int L, const float* w0,
-                                            const float* gamma, const float* stats_ws, const float* norm_ws, const float* mr_ws,
-                                            const void* dy0, float* part_ws, float* sums_ws, void* dz0, int T0, int P0, int C0,
-                                            advh_stream_t stream) {
+static int frontend_bwd_group_launch(const float* wave, int64_t wave_stride, int n_in, int B, int L, const float* w0,
+                                     const float* gamma, const float* stats_ws, const float* norm_ws, const float* mr_ws,
+                                     const void* dy0, long dy_lo, float* part_ws, float* sums_ws, void* dz0, long dz_lo, int T0, int P0,
+                                     int C0, advh_stream_t stream) {
     if (!wave || !w0 || !gamma || !stats_ws || !norm_ws || !mr_ws || !dy0 || !part_ws || !sums_ws || !dz0) return ADVH_EINVAL;
     if (B <= 0 || C0 <= 0 || C0 > 512 || (C0 & 1) || T0 != (L - K0) / S0 + 1 || P0 < T0) return ADVH_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     dim3 grid((P0 + TT - 1) / TT, B);
     hipLaunchKernelGGL(gn0_bwd_kernel<0>, grid, dim3(256), 0, s, wave, (long)wave_stride, n_in, L, (const float2*)stats_ws, w0,
                        (const float2*)norm_ws, (const float2*)mr_ws, gamma, (const _Float16*)dy0, (float2*)part_ws, (const float2*)nullptr,
-                       (_Float16*)nullptr, T0, P0, C0);
+                       (_Float16*)nullptr, T0, P0, C0, dy_lo, dz_lo);
     hipLaunchKernelGGL(gn0_reduce_kernel, dim3((C0 + 255) / 256, B), dim3(256), 0, s, (const float2*)part_ws, (float2*)sums_ws, (int)grid.x, C0);
     hipLaunchKernelGGL(gn0_bwd_kernel<1>, grid, dim3(256), 0, s, wave, (long)wave_stride, n_in, L, (const float2*)stats_ws, w0,
                        (const float2*)norm_ws, (const float2*)mr_ws, gamma, (const _Float16*)dy0, (float2*)nullptr, (const float2*)sums_ws,
-                       (_Float16*)dz0, T0, P0, C0);
+                       (_Float16*)dz0, T0, P0, C0, dy_lo, dz_lo);
     return ADVH_LAUNCH_CHECK();
+}
+
+extern "C" int advh_w2v2_frontend_bwd_group(const float* wave, int64_t wave_stride, int n_in, int B, int L, const float* w0,
+                                            const float* gamma, const float* stats_ws, const float* norm_ws, const float* mr_ws,
+                                            const void* dy0, float* part_ws, float* sums_ws, void* dz0, int T0, int P0, int C0,
+                                            advh_stream_t stream) {
+    return frontend_bwd_group_launch(wave, wave_stride, n_in, B, L, w0, gamma, stats_ws, norm_ws, mr_ws, dy0, 0, part_ws, sums_ws, dz0, 0,
+                                     T0, P0, C0, stream);
+}
+
+extern "C" int advh_w2v2_frontend_bwd_group_split(const float* wave, int64_t wave_stride, int n_in, int B, int L, const float* w0,
+                                                  const float* gamma, const float* stats_ws, const float* norm_ws, const float* mr_ws,
+                                                  const void* dy0, int64_t dy_lo, float* part_ws, float* sums_ws, void* dz0, int64_t dz_lo,
+                                                  int T0, int P0, int C0, advh_stream_t stream) {
+    if (dy_lo <= 0 || dz_lo <= 0 || dy_lo % 2 || dz_lo % 2) return ADVH_EINVAL;
+    return frontend_bwd_group_launch(wave, wave_stride, n_in, B, L, w0, gamma, stats_ws, norm_ws, mr_ws, dy0, dy_lo, part_ws, sums_ws, dz0,
+                                     dz_lo, T0, P0, C0, stream);
 }
 
 extern "C" int advh_wave_bwd(const float* g, const float* wave, int64_t wave_stride, int n_in, int B, int L, const float* stats_ws,

@@ -1604,7 +1604,6 @@ extern "C" int advh_gemm_f16(const advh_gemm_desc* d, int tile, advh_stream_t st
                                           tile == ADVH_TILE_256x128_PERSIST || tile == ADVH_TILE_256x256_W4))
         return ADVH_EUNSUPPORTED;                        // the two-level batch lives in gemm_f16_kernel only
     if (d->split) {                                      // fp32-class instance: split-format operands, 3 MFMAs per fragment pair
-        if (d->out_pre || d->dact_src) return ADVH_EUNSUPPORTED;      // the backward chain runs on the fp16 instances
         switch (tile) {
             case ADVH_TILE_128x128: return launch_x3<128, 128, 2, 2>(*d, s);
             case ADVH_TILE_256x64: return launch_x3<256, 64, 4, 1>(*d, s);

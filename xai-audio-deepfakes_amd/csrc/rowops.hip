@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const void* __restrict__
 // (the zero padding of the positional Conv1d, modeling_wav2vec2.py:326-379).
 __global__ __launch_bounds__(256) void posconv_gather_kernel(const float* __restrict__ h, _Float16* __restrict__ xg,
                                                              int B, int T, int H, int G, int K, int pad_left,
-                                                             const _Float16* __restrict__ dact_src, long xg_lo) {
+                                                             const _Float16* __restrict__ dact_src, long xg_lo, long dact_lo) {
     const int Cg = H / G, P = T + K, c4 = Cg / 4;
     const long total = (long)G * B * P * c4;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -101,9 +101,10 @@ __global__ __launch_bounds__(256) void posconv_gather_kernel(const float* __rest
             const long src = ((long)b * T + t) * H + g * Cg + c;
             float4 v = *(const float4*)(h + src);
             if (dact_src) {                              // backward: gradient w.r.t. the pre-GELU conv output
-                f16x4 z = *(const f16x4*)(dact_src + src);
-                v.x *= gelu_grad((float)z[0]); v.y *= gelu_grad((float)z[1]);
-                v.z *= gelu_grad((float)z[2]); v.w *= gelu_grad((float)z[3]);
+                float z[4];
+                load_h_rt<4>(dact_src, src, dact_lo, z);
+                v.x *= gelu_grad(z[0]); v.y *= gelu_grad(z[1]);
+                v.z *= gelu_grad(z[2]); v.w *= gelu_grad(z[3]);
             }
             o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
         }
@@ -233,25 +234,31 @@ extern "C" int advh_layernorm(const void* in, int in_is_f32, int64_t in_ld, cons
 }
 
 static int posconv_gather_launch(const float* h, void* xg, int64_t xg_lo, int B, int T, int H, int G, int K, int pad_left,
-                                 const void* dact_src, advh_stream_t stream) {
+                                 const void* dact_src, int64_t dact_lo, advh_stream_t stream) {
     if (!h || !xg || B <= 0 || T <= 0 || H <= 0 || G <= 0 || H % G || (H / G) % 8 || K <= 0 || K % 2 || pad_left < 0 || pad_left > K) return ADVH_EINVAL;
     long total = (long)G * B * (T + K) * (H / G / 4);
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(posconv_gather_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, h, (_Float16*)xg, B, T, H, G, K, pad_left,
-                       (const _Float16*)dact_src, (long)xg_lo);
+                       (const _Float16*)dact_src, (long)xg_lo, (long)dact_lo);
     return ADVH_LAUNCH_CHECK();
 }
 
 extern "C" int advh_posconv_gather(const float* h, void* xg, int B, int T, int H, int G, int K, int pad_left,
                                    const void* dact_src, advh_stream_t stream) {
-    return posconv_gather_launch(h, xg, 0, B, T, H, G, K, pad_left, dact_src, stream);
+    return posconv_gather_launch(h, xg, 0, B, T, H, G, K, pad_left, dact_src, 0, stream);
 }
 
 extern "C" int advh_posconv_gather_split(const float* h, void* xg, int64_t xg_lo, int B, int T, int H, int G, int K, int pad_left,
                                          advh_stream_t stream) {
     if (xg_lo <= 0 || xg_lo % 4) return ADVH_EINVAL;
-    return posconv_gather_launch(h, xg, xg_lo, B, T, H, G, K, pad_left, nullptr, stream);
+    return posconv_gather_launch(h, xg, xg_lo, B, T, H, G, K, pad_left, nullptr, 0, stream);
+}
+
+extern "C" int advh_posconv_gather_bwd_split(const float* dh, void* xg, int64_t xg_lo, int B, int T, int H, int G, int K, int pad_left,
+                                             const void* dact_src, int64_t dact_lo, advh_stream_t stream) {
+    if (xg_lo <= 0 || xg_lo % 4 || !dact_src || dact_lo <= 0 || dact_lo % 4) return ADVH_EINVAL;
+    return posconv_gather_launch(dh, xg, xg_lo, B, T, H, G, K, pad_left, dact_src, dact_lo, stream);
 }
 
 extern "C" int advh_pool_logreg(const float* h, const float* coef, float intercept, float* logit, float* prob,
