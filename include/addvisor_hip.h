@@ -533,6 +533,26 @@ int advh_unet_head_wgrad(const float* dlogit, const void* y1, int64_t total, flo
 int advh_unet_stem_wgrad(const void* dz, int Fq, int Tq, int B, int H, int W, const float* mag, int PH, int PW,
                          float* partial, float* dw, advh_stream_t stream);
 
+/* fp32-class training step (train_addvisor.py:363-378 runs the decoder's forward and loss.backward() in fp32): the same
+ * kernels on split-format maps [2][B][H+2PH][W+2PW][C] (hi + lo fp16 planes, csrc/device_math.h; `*_lo` = distance in
+ * elements between the planes), so LeakyReLU takes the branch the fp32 reference takes and the weight / activation
+ * gradients keep ~22 bits.  The convolutions, dgrads and split-K wgrads are advh_gemm_f16 launches with desc.split = 1;
+ * advh_transpose_gather is called once per plane.  g_a is a split map here.                                              */
+int advh_bn_stats_split(const void* z, int64_t z_lo, const advh_map_geom* g, float* partial, float* sums, advh_stream_t stream);
+int advh_bn_apply_split(const void* z, int64_t z_lo, const advh_map_geom* g, const float* coef, float slope, void* a, int64_t a_lo,
+                        advh_stream_t stream);
+int advh_bn_bwd_sums_split(const void* z, int64_t z_lo, const void* g_a, int64_t g_lo, const advh_map_geom* g, const float* coef,
+                           float slope, float* partial, float* sums, advh_stream_t stream);
+int advh_bn_bwd_apply_split(const void* z, int64_t z_lo, const void* g_a, int64_t g_lo, const advh_map_geom* g, const float* coef,
+                            const float* coef_b, float slope, void* dz, int64_t dz_lo, int64_t d_sB, int64_t d_sH, int64_t d_sW,
+                            int64_t d_c0, advh_stream_t stream);
+int advh_unet_head_bwd_split(const float* dmask, const float* mask, const float* w32, float scale, int64_t total, float* dlogit,
+                             void* dy1, int64_t dy_lo, advh_stream_t stream);
+int advh_unet_head_wgrad_split(const float* dlogit, const void* y1, int64_t y_lo, int64_t total, float* partial, float* dw33,
+                               advh_stream_t stream);
+int advh_unet_stem_wgrad_split(const void* dz, int64_t dz_lo, int Fq, int Tq, int B, int H, int W, const float* mag, int PH, int PW,
+                               float* partial, float* dw, advh_stream_t stream);
+
 /* Weight gradient of a 3x3 stride-1 "same" Conv2d, C_in = C_out = C in {32, 64}, without transposed copies in HBM:
  * dw[kh*3+kw][co][ci] = sum_p dz[p][co] * x[p + (kh-1, kw-1)][ci].  X and DZ are zero-haloed channels-last fp16 maps of
  * the same interior [B][H][W_] with their own halos (>= 1); both MFMA operands are read from LDS tiles with

@@ -1,8 +1,9 @@
 """GPU parity of the LMAC loss BACKWARD (loss_function.py:36-66 under
 train_addvisor.py:374-378) against torch autograd run through the CPU oracle.
 
-Stated tolerance: the chain runs fp16 GEMM operands with fp32 accumulation, so gradients are compared by
-max |err| / max |ref| <= 3e-2 and cosine similarity >= 0.999; the ISTFT adjoint alone is fp32: 1e-4."""
+Stated tolerance: in the default fp32-class mode (split-format operands and gradients, the reference's fp32 autograd class)
+gradients are compared by max |err| / max |ref| <= 1e-4 and cosine similarity > 0.999999; with ADDVISOR_PRECISION=f16 (fp16
+GEMM operands and gradients) 3e-2 / 0.999; the ISTFT adjoint alone is fp32: 1e-4."""
 import os
 
 import numpy as np
@@ -84,13 +85,14 @@ def test_lmac_loss_backward_matches_oracle_autograd(gpu_device, tiny_runtime):
         xh = xhat0.clone().to(gpu_device).requires_grad_(True)
         total, losses, _ = loss.loss_function(xh, mag, ph, cp)
         total.backward()
-    assert (losses.detach().cpu() - losses_ref.detach()).abs().max().item() < 1e-2
+    f32 = runtime.hip_embedder_grad().precision == "f32"
+    assert (losses.detach().cpu() - losses_ref.detach()).abs().max().item() < (1e-5 if f32 else 1e-2)
     gx = xh.grad.cpu()
     err = relerr(gx, gx_ref)
-    cos = F.cosine_similarity(gx.flatten(), gx_ref.flatten(), dim=0).item()
-    print(f"d total / d xhat: max rel err {err:.3e}, cosine {cos:.6f}, |ref| max {gx_ref.abs().max():.3e}")
-    assert err < 3e-2 and cos > 0.999
-    assert torch.allclose(loss.w_raw.grad.cpu(), gw_ref, atol=2e-3)
+    cos = F.cosine_similarity(gx.double().flatten(), gx_ref.double().flatten(), dim=0).item()
+    print(f"d total / d xhat [{runtime.hip_embedder_grad().precision}]: max rel err {err:.3e}, cosine {cos:.8f}, |ref| max {gx_ref.abs().max():.3e}")
+    assert (err < 1e-4 and cos > 0.999999) if f32 else (err < 3e-2 and cos > 0.999)
+    assert torch.allclose(loss.w_raw.grad.cpu(), gw_ref, atol=1e-5 if f32 else 2e-3)
     # a descent step along the HIP gradient lowers the HIP loss (end-to-end sanity of sign and scale)
     with torch.no_grad():
         step = 0.05 / gx.abs().max()

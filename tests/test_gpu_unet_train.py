@@ -1,6 +1,11 @@
 """GPU parity of the U-Net TRAINING step on the HIP kernels (addvisor.py:12-84 in train()
 mode under train_addvisor.py:364-378).
 
+Default precision = the fp32-class mode (split-format maps and gradients, three MFMAs per product: the reference trains in
+fp32), where BOTH levels below are tight: per layer 2e-5 of max|ref|, end to end against fp32 autograd through the CPU oracle
+cosine >= 0.9999 and relative L2 <= 1e-3 for EVERY parameter with the reference's LeakyReLU(0.2).  The fp16 mode
+(precision="f16") keeps round 1's two-level statement:
+
 Two levels, because LeakyReLU makes an end-to-end gradient comparison at fp16 inherently loose: a pre-activation that
 the fp16 forward rounds across zero flips the local slope (1 vs 0.2) on a ~4e-4 fraction of the elements, a sparse
 error of relative L2 size sqrt(fraction) ~ 2 % per layer that no kernel can avoid (torch AMP shows the same).
@@ -18,14 +23,14 @@ import torch
 import torch.nn.functional as F
 from torch.nn import grad as nngrad
 
-from addvisor_hip import synthetic as syn
+from addvisor_hip import gemm as G, synthetic as syn
 from addvisor_hip.unet_train import HipUNetTrain, BN_EPS, SLOPE
 from oracle import unet_ref
 
 pytestmark = pytest.mark.gpu
 
 
-def setup(dev, B, H, W, seed):
+def setup(dev, B, H, W, seed, precision="f32"):
     sd = syn.unet_weights(seed=seed)
     gen = torch.Generator().manual_seed(seed + 1)
     mag = torch.rand(B, H, W, generator=gen) * 3.0
@@ -40,13 +45,15 @@ def setup(dev, B, H, W, seed):
         ref_grads = dict(zip(names, torch.autograd.grad((ref_mask * dmask).sum(), [ref_sd[k] for k in names], allow_unused=True)))
 
     params = {k: v.clone().float().to(dev) for k, v in sd.items()}
-    net = HipUNetTrain(params, dev)
+    net = HipUNetTrain(params, dev, precision=precision)
+    assert net.precision == precision
     return net, params, mag, target, dmask, ref_mask.detach(), ref_grads
 
 
 def interior(f, t=None):
     t = f.t if t is None else t
-    return t[:, f.PH:f.PH + f.H, f.PW:f.PW + f.W].float().cpu().permute(0, 3, 1, 2).contiguous()     # NCHW fp32
+    t = G.join_planes(t) if f.split else t.float()            # fp32-class mode: [2, B, Hp, Wp, C] plane pair
+    return t[:, f.PH:f.PH + f.H, f.PW:f.PW + f.W].cpu().permute(0, 3, 1, 2).contiguous()     # NCHW fp32
 
 
 def close(a, b, tol, what):
@@ -56,9 +63,12 @@ def close(a, b, tol, what):
     return err / (scale + 1e-30)
 
 
+@pytest.mark.parametrize("precision", ["f32", "f16"])
 @pytest.mark.parametrize("B,H,W,seed", [(2, 32, 8, 5), (3, 64, 24, 7)])
-def test_every_layer_backward_is_exact_on_its_own_operands(gpu_device, B, H, W, seed):
-    net, params, mag, target, dmask, _, _ = setup(gpu_device, B, H, W, seed)
+def test_every_layer_backward_is_exact_on_its_own_operands(gpu_device, B, H, W, seed, precision):
+    net, params, mag, target, dmask, _, _ = setup(gpu_device, B, H, W, seed, precision)
+    TOL = 2e-5 if precision == "f32" else 4e-3
+    wq = (lambda w: w) if precision == "f32" else (lambda w: w.half().float())     # the operand precision of the dgrad weights
     net.forward(mag.to(gpu_device), H=H, W=W)
     grads = net.backward(dmask.to(gpu_device))
     ws = net._workspace(B, H, W)
@@ -77,10 +87,10 @@ def test_every_layer_backward_is_exact_on_its_own_operands(gpu_device, B, H, W, 
             x, gy = interior(L["src"]), interior(L["gdst"])
             w = params[name + ".weight"].cpu()
             dw = torch.einsum("bchw,bdhiwj->cdij", x, gy.view(B, gy.shape[1], x.shape[2], sh, x.shape[3], sw))
-            worst = max(worst, close(grads[name + ".weight"].cpu() * S, dw, 4e-3, name + ".weight"))
-            worst = max(worst, close(grads[name + ".bias"].cpu() * S, gy.sum((0, 2, 3)), 4e-3, name + ".bias"))
+            worst = max(worst, close(grads[name + ".weight"].cpu() * S, dw, TOL, name + ".weight"))
+            worst = max(worst, close(grads[name + ".bias"].cpu() * S, gy.sum((0, 2, 3)), TOL, name + ".bias"))
             a = acc.setdefault(id(L["gsrc"]), [L["gsrc"], 0.0])
-            a[1] = a[1] + F.conv2d(gy, w.half().float(), stride=(sh, sw))
+            a[1] = a[1] + F.conv2d(gy, wq(w), stride=(sh, sw))
             continue
         cname, bname, dst = L["cname"], L["bname"], L["dst"]
         (KH, KW), (sh, sw), pad, dil = L["k"], L["stride"], L["pad"], L["dil"]
@@ -96,9 +106,9 @@ def test_every_layer_backward_is_exact_on_its_own_operands(gpu_device, B, H, W, 
             gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
             y = F.leaky_relu(F.batch_norm(zr, None, None, gr, br, True, 0.0, BN_EPS), SLOPE)
             dzr, dgr, dbr = torch.autograd.grad((y * gin).sum(), [zr, gr, br])
-        worst = max(worst, close(dz.double(), dzr, 4e-3, cname + " dz"))
-        worst = max(worst, close(grads[bname + ".weight"].cpu().double() * S, dgr, 4e-3, bname + ".weight"))
-        worst = max(worst, close(grads[bname + ".bias"].cpu().double() * S, dbr, 4e-3, bname + ".bias"))
+        worst = max(worst, close(dz.double(), dzr, TOL, cname + " dz"))
+        worst = max(worst, close(grads[bname + ".weight"].cpu().double() * S, dgr, TOL, bname + ".weight"))
+        worst = max(worst, close(grads[bname + ".bias"].cpu().double() * S, dbr, TOL, bname + ".bias"))
         # weight gradient on HIP's own input activations and dz
         w = params[cname + ".weight"].cpu()
         if L["srcs"] == ["mag"]:
@@ -106,12 +116,12 @@ def test_every_layer_backward_is_exact_on_its_own_operands(gpu_device, B, H, W, 
         else:
             x = torch.cat([interior(m[s]) for s in L["srcs"]], 1)[:, :w.shape[1]]
         dw = nngrad.conv2d_weight(x, w.shape, dz, stride=(sh, sw), padding=pad, dilation=dil)
-        worst = max(worst, close(grads[cname + ".weight"].cpu() * S, dw, 4e-3, cname + ".weight"))
+        worst = max(worst, close(grads[cname + ".weight"].cpu() * S, dw, TOL, cname + ".weight"))
         assert grads[cname + ".bias"].abs().max().item() == 0.0
         if L["srcs"] == ["mag"]:
             continue
         # activation gradients: contributions of this layer to each source map
-        dx = nngrad.conv2d_input(x.shape, w.half().float(), dz, stride=(sh, sw), padding=pad, dilation=dil)
+        dx = nngrad.conv2d_input(x.shape, wq(w), dz, stride=(sh, sw), padding=pad, dilation=dil)
         lo = 0
         for s in L["srcs"]:
             c = g[s].C
@@ -119,12 +129,13 @@ def test_every_layer_backward_is_exact_on_its_own_operands(gpu_device, B, H, W, 
             a[1] = a[1] + dx[:, lo:lo + c]
             lo += m[s].C
     for f, ref in acc.values():
-        worst = max(worst, close(interior(f), ref, 4e-3, "activation gradient"))
-    print(f"per-layer backward parity B={B} {H}x{W}: worst max-rel err {worst:.2e}; loss scale 2^{int(round(np.log2(S)))}")
+        worst = max(worst, close(interior(f), ref, TOL, "activation gradient"))
+    print(f"per-layer backward parity [{precision}] B={B} {H}x{W}: worst max-rel err {worst:.2e}; loss scale 2^{int(round(np.log2(S)))}")
 
 
+@pytest.mark.parametrize("precision", ["f32", "f16"])
 @pytest.mark.parametrize("B,H,W,seed,slope", [(2, 32, 8, 5, 0.2), (3, 64, 24, 7, 0.2), (3, 64, 24, 7, 1.0)])
-def test_train_step_against_oracle_autograd(gpu_device, monkeypatch, B, H, W, seed, slope):
+def test_train_step_against_oracle_autograd(gpu_device, monkeypatch, B, H, W, seed, slope, precision):
     """slope 0.2 = the reference network.  slope 1.0 = the kink-free control: the same kernels, launches and data
     flow with LeakyReLU turned into the identity on both sides, where end-to-end agreement must be (and is) tight."""
     import addvisor_hip.unet_train as UT
@@ -132,12 +143,13 @@ def test_train_step_against_oracle_autograd(gpu_device, monkeypatch, B, H, W, se
         lrelu = F.leaky_relu
         monkeypatch.setattr(UT, "SLOPE", slope)
         monkeypatch.setattr(unet_ref.F, "leaky_relu", lambda x, s=0.2, **kw: lrelu(x, slope))
-    net, params, mag, target, dmask, ref_mask, ref_grads = setup(gpu_device, B, H, W, seed)
+    net, params, mag, target, dmask, ref_mask, ref_grads = setup(gpu_device, B, H, W, seed, precision)
+    f32 = precision == "f32"
     rm0 = params["e2.block.1.running_mean"].clone()
     mask = net.forward(mag.to(gpu_device), H=H, W=W)
     err = (mask.cpu() - ref_mask).abs().max().item()
-    print(f"train-mode forward B={B} {H}x{W} slope {slope}: mask max err {err:.2e}")
-    assert err <= 1.5e-2
+    print(f"train-mode forward [{precision}] B={B} {H}x{W} slope {slope}: mask max err {err:.2e}")
+    assert err <= (2e-5 if f32 else 1.5e-2)
     assert not torch.equal(params["e2.block.1.running_mean"], rm0)                   # running statistics were updated
     grads = net.backward(dmask.to(gpu_device))
     worst = (1.0, "", 0.0)
@@ -151,11 +163,13 @@ def test_train_step_against_oracle_autograd(gpu_device, monkeypatch, B, H, W, se
         rel2 = ((gk - r).norm() / r.norm()).item()
         if cos < worst[0]:
             worst = (cos, k, rel2)
-        if slope == 1.0:
+        if f32:                                                  # fp32-class mode: tight with the reference's LeakyReLU(0.2) too
+            assert cos >= 0.9999 and rel2 <= 1e-3, (k, cos, rel2)
+        elif slope == 1.0:
             assert cos >= 0.9999 and rel2 <= 1.5e-2, (k, cos, rel2)
         else:
             assert cos >= 0.95, (k, cos, rel2)
-    print(f"end-to-end parameter gradients (slope {slope}): worst cosine {worst[0]:.6f} (rel L2 {worst[2]:.4f}) at {worst[1]}")
+    print(f"end-to-end parameter gradients [{precision}] (slope {slope}): worst cosine {worst[0]:.6f} (rel L2 {worst[2]:.4f}) at {worst[1]}")
     # a small step along the negative HIP gradient lowers the loss mean((mask - target)^2)
     loss0 = ((mask.cpu() - target) ** 2).mean().item()
     gn = max(v.abs().max().item() for v in grads.values())

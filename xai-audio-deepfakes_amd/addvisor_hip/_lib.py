@@ -104,6 +104,13 @@ SIGNATURES = {
     "advh_hifigan_conv_post_split": (_i, [_p, _i64, _p, _f, _p, _i, _i, _i, _i, _i, _p]),
     "advh_unet_head_split": (_i, [_p, _i64, _i, _i, _i, _i, _i, _p, _f, _p, _p, _p]),
     "advh_upconv21_tile_lds_bytes": (_i, []),
+    "advh_bn_stats_split": (_i, [_p, _i64, _p, _p, _p, _p]),
+    "advh_bn_apply_split": (_i, [_p, _i64, _p, _p, _f, _p, _i64, _p]),
+    "advh_bn_bwd_sums_split": (_i, [_p, _i64, _p, _i64, _p, _p, _f, _p, _p, _p]),
+    "advh_bn_bwd_apply_split": (_i, [_p, _i64, _p, _i64, _p, _p, _p, _f, _p, _i64, _i64, _i64, _i64, _i64, _p]),
+    "advh_unet_head_bwd_split": (_i, [_p, _p, _p, _f, _i64, _p, _p, _i64, _p]),
+    "advh_unet_head_wgrad_split": (_i, [_p, _p, _i64, _i64, _p, _p, _p]),
+    "advh_unet_stem_wgrad_split": (_i, [_p, _i64, _i, _i, _i, _i, _i, _p, _i, _i, _p, _p, _p]),
     "advh_layernorm_bwd_split": (_i, [_p, _i, _i64, _p, _i, _i64, _p, _p, _i, _p, _p, _i64, _p, _p, _i64, _i, _i, _f, _i, _i, _p]),
     "advh_attention_bwd_split": (_i, [_p, _i64, _p, _i64, _p, _i64, _i, _i, _i, _i, _p]),
     "advh_pool_logreg_bwd_split": (_i, [_p, _p, _p, _p, _i64, _i, _i, _i, _p]),

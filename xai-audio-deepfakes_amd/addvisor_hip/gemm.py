@@ -287,20 +287,20 @@ class GemmPlan:
 
     def load_weights(self, w2: torch.Tensor, bias: Optional[torch.Tensor] = None):
         """Re-pack ``w2 [nz, N, K]`` (a tensor on the plan's device, any float dtype) into the plan's fp16 operand in
-        place, with the wide-epilogue row permutation if the plan uses it -- the per-step weight refresh of the
-        training path (no host round trip; a handful of torch copy kernels)."""
+        place (both planes of the split format for an fp32-class plan), with the wide-epilogue row permutation if the plan
+        uses it -- the per-step weight refresh of the training path (no host round trip; a handful of torch copy kernels)."""
         N, K = self.desc.N, self.K
-        assert not self.split, "the training path repacks fp16 weights only"
         assert w2.shape == (self.desc.nz, N, K) and w2.device == self.w.device, (w2.shape, (self.desc.nz, N, K))
+        w16 = split_planes(w2) if self.split else w2.to(torch.float16)           # [2, nz, N, K] | [nz, N, K]
         if self.desc.wide:
             if not hasattr(self, "_perm"):
-                src = packed_row_channel(self.w.shape[1])
+                src = packed_row_channel(self.w.shape[-2])
                 keep = np.nonzero(src < N)[0]
                 self._perm = (torch.from_numpy(keep).to(self.w.device), torch.from_numpy(src[keep]).to(self.w.device))
             dst_rows, src_rows = self._perm
-            self.w[:, dst_rows, :K] = w2.to(torch.float16)[:, src_rows]
+            self.w[..., dst_rows, :K] = w16[..., src_rows, :]
         else:
-            self.w[:, :N, :K] = w2.to(torch.float16)
+            self.w[..., :N, :K] = w16
         if bias is not None:
             self.bias.copy_(bias.reshape(self.bias.shape).to(torch.float32))
 

@@ -22,9 +22,33 @@ from . import ops
 from .embedder_grad import EmbedderGrad
 
 
+class LossScaler:
+    """Power-of-two scale of the gradients inside the frozen embedder's backward, GradScaler style: backed off by 1/16 when
+    the input gradient comes back non-finite (the planes between the dgrad GEMMs have fp16's exponent range in both
+    precision modes) and KEPT for the following steps, doubled again after ``growth_interval`` clean steps up to the
+    initial value.  Powers of two are exact, so the scale never changes a finite result."""
+
+    def __init__(self, scale: float = 4096.0, growth_interval: int = 200, min_scale: float = 2.0 ** -20):
+        self.initial = self.scale = float(scale)
+        self.growth_interval, self.min_scale = int(growth_interval), float(min_scale)
+        self.good_steps = 0
+
+    def backoff(self) -> bool:
+        self.good_steps = 0
+        if self.scale * (1.0 / 16.0) < self.min_scale:
+            return False
+        self.scale *= 1.0 / 16.0
+        return True
+
+    def good(self):
+        self.good_steps += 1
+        if self.good_steps >= self.growth_interval and self.scale < self.initial:
+            self.scale, self.good_steps = min(self.initial, self.scale * 2.0), 0
+
+
 class _LMACTerms(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, mask, mag, phase, class_pred, eg: EmbedderGrad, length: int, hop: int, win: int, loss_scale: float):
+    def forward(ctx, mask, mag, phase, class_pred, eg: EmbedderGrad, length: int, hop: int, win: int, scaler: LossScaler):
         B = mask.shape[0]
         need = ctx.needs_input_grad[0]
         m = mask.detach().contiguous()
@@ -36,17 +60,20 @@ class _LMACTerms(torch.autograd.Function):
         terms = torch.stack([bce(l_rel, cp), bce(l_irr, 1 - cp), m.abs().mean()])
         if need:
             seed = torch.cat([torch.sigmoid(l_rel) - cp, torch.sigmoid(l_irr) - (1 - cp)]) / B
-            g = eg.backward(loss_scale, seed=seed)                          # dL/d wave, [2B, length]
-            # fp16 gradients between the dgrad GEMMs: an overflow shows up as inf / NaN here.  Back the power-of-two scale
-            # off (exact) and redo the backward rather than hand a poisoned gradient to the optimiser (GradScaler's rule).
-            tries = 0
-            while not bool(torch.isfinite(g).all()) and tries < 6:
-                loss_scale *= 1.0 / 16.0
-                tries += 1
-                g = eg.backward(loss_scale, seed=seed)
-            if tries and not bool(torch.isfinite(g).all()):
-                raise FloatingPointError("LMAC loss backward: non-finite input gradient at every loss scale down to "
-                                         f"{loss_scale:g}")
+            # One flag read per step (the only host synchronisation of the loss): an overflow shows up as inf / NaN in the input
+            # gradient.  Back the power-of-two scale off (exact), keep it for the following steps and redo this backward
+            # rather than hand a poisoned gradient to the optimiser.  A NaN that is not an overflow (bad input) fails at once
+            # when the forward logits are already non-finite.
+            g = eg.backward(scaler.scale, seed=seed)                        # dL/d wave, [2B, length]
+            ok_fwd, ok = torch.stack([torch.isfinite(logits).all(), torch.isfinite(g).all()]).tolist()   # ONE read for both flags
+            if not ok_fwd:
+                raise FloatingPointError("LMAC loss: non-finite classifier logits in the forward pass (bad input or weights)")
+            while not ok:
+                if not scaler.backoff():
+                    raise FloatingPointError(f"LMAC loss backward: non-finite input gradient at every loss scale down to {scaler.scale:g}")
+                g = eg.backward(scaler.scale, seed=seed)
+                ok = bool(torch.isfinite(g).all())
+            scaler.good()
             g_in = ops.istft_masked_bwd(g[:B], mag, phase, m, 0, domain="linear", hop=hop, win=win)
             g_out = ops.istft_masked_bwd(g[B:], mag, phase, m, 1, domain="linear", hop=hop, win=win)
             ctx.save_for_backward(g_in, g_out, m)
@@ -60,11 +87,12 @@ class _LMACTerms(torch.autograd.Function):
 
 
 def lmac_terms(mask: torch.Tensor, mag: torch.Tensor, phase: torch.Tensor, class_pred: torch.Tensor, eg: EmbedderGrad,
-               length: int, hop: int = 322, win: int = 644, loss_scale: float = 4096.0) -> torch.Tensor:
+               length: int, hop: int = 322, win: int = 644, loss_scale=4096.0) -> torch.Tensor:
     """``[l_in, l_out, l1]`` (loss_function.py:54-59) for ``mask [B, Fm, Tm]`` (the U-Net crop; bins outside it are
     mask 0), differentiable w.r.t. ``mask``."""
     if mask.dim() != 3:
         raise ValueError("mask must be [B, Fm, Tm]")
     dev = eg.emb.dev
     f32 = lambda t: t.to(dev, torch.float32).contiguous()
-    return _LMACTerms.apply(f32(mask), f32(mag), f32(phase), f32(class_pred), eg, int(length), hop, win, loss_scale)
+    scaler = loss_scale if isinstance(loss_scale, LossScaler) else LossScaler(float(loss_scale))   # a LossScaler persists back-offs across steps
+    return _LMACTerms.apply(f32(mask), f32(mag), f32(phase), f32(class_pred), eg, int(length), hop, win, scaler)

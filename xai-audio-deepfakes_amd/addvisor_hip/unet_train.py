@@ -19,6 +19,13 @@ Backward  per layer, in reverse:
           ConvTranspose2d (kernel = stride): dgrad is a strided convolution, wgrad the same transposed GEMM with the
           sub-pixel taps gathered by the transpose.
 Gradients between kernels are fp16 scaled by a power of two chosen from the incoming mask gradient; sums are fp32/fp64.
+
+Precision (``precision=``, default ``ADDVISOR_PRECISION`` = f32): the reference trains in fp32 (train_addvisor.py:363-378).
+"f32" = the fp32-class mode: every map above is a split-format plane pair ``[2, B, Hp, Wp, C]`` (hi + lo * 2^-11, ~22 bits),
+the forward convolutions, dgrads and split-K wgrads are the three-MFMA launches (``desc.split``), the BatchNorm / head / stem
+kernels read and write plane pairs, the operand transposes run once per plane -- so LeakyReLU takes the branch the fp32
+reference takes and parameter gradients agree with fp32 autograd to ~1e-5 instead of the fp16 mode's cosine 0.98.  "f16" =
+fp16 maps and gradients (half the bytes, a third of the MFMAs; the LDS-tile wgrad kernel is fp16-only).
 """
 from __future__ import annotations
 
@@ -29,6 +36,7 @@ from typing import Dict, List, Optional, Tuple
 import torch
 
 from . import _lib, gemm as G
+from .embedder import default_precision
 
 SLOPE = 0.2
 WGRAD_TILES = True   # 3x3 square 32/64-channel layers: wgrad on the LDS-tile kernel (ds_read_b64_tr_b16) instead of transposes + split-K GEMM
@@ -107,7 +115,7 @@ class _SplitKGemm:
     A and W are position-major fp16 matrices on the device (``advh_transpose_gather`` outputs)."""
 
     def __init__(self, Mrows: int, N: int, Kc: int, nz: int, a_ld: int, a_col: int, w_ld: int, device, groups: int = 1,
-                 group_off: int = 0):
+                 group_off: int = 0, split: bool = False):
         """``groups`` > 1: the A rows come in ``groups`` blocks of ``Mrows`` (the vertical taps of a convolution); block
         ``i`` reads the same matrix rows shifted by ``i * group_off`` columns (the tap's K offset), so all taps are one launch."""
         assert Kc % G.BK == 0 and a_ld % 8 == 0 and a_col % 8 == 0 and a_col >= 0 and w_ld % 8 == 0 and group_off % 8 == 0
@@ -123,10 +131,15 @@ class _SplitKGemm:
         d.o_sB, d.o_sH, d.o_sW, d.o_c0, d.o_sNhi, d.o_sZ = 0, Mrows * N, N, 0, 0, Mrows * groups * N
         d.n_div, d.nz, d.act, d.slope = G.round_up(N, 4), nz, 0, 0.0
         d.ktab_identity, d.wide = 1, 0
+        d.split = int(split)
+        self.split = split
         self.desc, self.flops = d, 2.0 * Mrows * groups * N * Kc * nz
 
     def run(self, A: torch.Tensor, W: torch.Tensor, out_f: torch.Tensor):
         d = self.desc
+        if self.split:                                     # plane pairs [2, rows, ld]: lo plane = stride(0) elements behind
+            assert A.shape[0] == 2 and W.shape[0] == 2 and A.stride(0) % 8 == 0
+            d.a_lo[0], d.w_lo, d.o_lo = A.stride(0) // 8, W.stride(0), 0
         d.A0, d.A1, d.W, d.ktab = A.data_ptr(), None, W.data_ptr(), self.ktab.data_ptr()
         d.bias = d.resid = d.out_h = d.out_h2 = d.out_pre = d.dact_src = None
         d.out_f = out_f.data_ptr()
@@ -149,9 +162,13 @@ class HipUNetTrain:
     ``params``: live fp32 device tensors keyed like the module's ``state_dict`` (weights, biases, BatchNorm affine and
     running buffers); they are read at every ``forward`` and the running statistics are updated in place."""
 
-    def __init__(self, params: Dict[str, torch.Tensor], device):
+    def __init__(self, params: Dict[str, torch.Tensor], device, precision: Optional[str] = None):
         _lib.init()
         self.dev, self.p = device, params
+        self.precision = precision or default_precision()
+        if self.precision not in ("f16", "f32"):
+            raise ValueError("precision must be 'f16' or 'f32'")
+        self.split = self.precision == "f32"
         self.nparts = _lib.lib().advh_bn_partial_count()
         self._ws: Dict[Tuple[int, int, int], dict] = {}
         self._last = None
@@ -164,8 +181,9 @@ class HipUNetTrain:
             return self._ws[key]
         if H % 16 or W % 4:
             raise ValueError("U-Net input needs H % 16 == 0 and W % 4 == 0 (SURVEY.md D2)")
-        dev, p = self.dev, self.p
-        F = lambda h, w, c, ph, pw: G.FMap(B, h, w, c, ph, pw).alloc(dev)
+        dev, p, sp = self.dev, self.p, self.split
+        pl = (2,) if sp else ()
+        F = lambda h, w, c, ph, pw: G.FMap(B, h, w, c, ph, pw, split=sp).alloc(dev)
         geo = dict(                                            # activation maps: the geometry of addvisor_hip/unet.py
             x1a=(H // 2, W, 32, 1, 1), x1=(H // 2, W, 32, 2, 1), x2a=(H // 4, W, 64, 1, 1), x2=(H // 4, W, 64, 1, 1),
             x3a=(H // 8, W // 2, 128, 1, 1), x3=(H // 8, W // 2, 128, 1, 1), x4a=(H // 16, W // 4, 256, 1, 1),
@@ -177,8 +195,8 @@ class HipUNetTrain:
         m = {k: F(*v) for k, v in geo.items()}                 # activations
         z, g = {}, {}
         for k, (h, w, c, ph, pw) in geo.items():                # gradient w.r.t. the activation map: fp32 where a BatchNorm
-            f = G.FMap(B, h, w, 32 if k == "u1" else c, ph, pw)  # backward consumes it (its mean is subtracted there),
-            f.t = torch.zeros((B, f.Hp, f.Wp, f.C), dtype=torch.float16 if (k.startswith("u") or not G32) else torch.float32, device=dev)
+            f = G.FMap(B, h, w, 32 if k == "u1" else c, ph, pw, split=sp)  # backward consumes it (its mean is subtracted there),
+            f.t = torch.zeros(pl + (B, f.Hp, f.Wp, f.C), dtype=torch.float16 if (sp or k.startswith("u") or not G32) else torch.float32, device=dev)
             g[k] = f                                             # fp16 where it is only a GEMM operand (the upsampled maps)
         layers = []
         for row in _CONVS:
@@ -199,7 +217,8 @@ class HipUNetTrain:
         return ws
 
     def _plan_conv(self, cname, bname, srcs, dst, k, stride, pad, dil, m, z, g, B, H, W) -> dict:
-        dev, p = self.dev, self.p
+        dev, p, sp = self.dev, self.p, self.split
+        pl = (2,) if sp else ()
         (KH, KW), (sh, sw), (ph, pw), (dh, dw) = k, stride, pad, dil
         L = dict(kind="conv", cname=cname, bname=bname, srcs=srcs, dst=dst, k=k, stride=stride, pad=pad, dil=dil)
         Cout = p[cname + ".weight"].shape[0]
@@ -215,12 +234,12 @@ class HipUNetTrain:
         # INPUT-size grid with dz scattered at (sh*h, sw*w) for a strided layer; halo = the dgrad convolution's padding
         Hd, Wd = (m[dst].H, m[dst].W) if (sh, sw) == (1, 1) else (m[dst].H * sh, m[dst].W * sw)
         if stem:
-            L["dz"] = G.FMap(B, m[dst].H, m[dst].W, Cout, 0, 0).alloc(dev)                   # dense: only the stem wgrad reads it
+            L["dz"] = G.FMap(B, m[dst].H, m[dst].W, Cout, 0, 0, split=sp).alloc(dev)         # dense: only the stem wgrad reads it
             L["dz_strides"] = (L["dz"].Hp * L["dz"].Wp * Cout, L["dz"].Wp * Cout, Cout, 0)
             L["stem_part"] = torch.empty(self.nparts * 480, dtype=torch.float32, device=dev)
             return L
         pph, ppw = dh * (KH - 1) - ph, dw * (KW - 1) - pw
-        dzm = G.FMap(B, Hd, Wd, Cout, pph, ppw).alloc(dev)
+        dzm = G.FMap(B, Hd, Wd, Cout, pph, ppw, split=sp).alloc(dev)
         L["dz"] = dzm
         L["dz_strides"] = (dzm.Hp * dzm.Wp * Cout, sh * dzm.Wp * Cout, sw * Cout, (pph * dzm.Wp + ppw) * Cout)
         # ---- dgrad plans (one per source; the 40-channel d1 concat map only needs its 32 up-sampled channels)
@@ -236,7 +255,7 @@ class HipUNetTrain:
         L["Cin"] = Cin
         # ---- wgrad, 3x3 stride-1 square 32 / 64-channel layers: LDS-tile kernel with transposing operand reads, no copies
         f0 = m[srcs[0]]
-        if (WGRAD_TILES and len(srcs) == 1 and k == (3, 3) and stride == (1, 1) and dil == (1, 1) and Cin == Cout and Cout in (32, 64)
+        if (WGRAD_TILES and not sp and len(srcs) == 1 and k == (3, 3) and stride == (1, 1) and dil == (1, 1) and Cin == Cout and Cout in (32, 64)
                 and f0.PH >= 1 and f0.PW >= 1):
             nparts = _lib.lib().advh_conv_wgrad2d_parts(Cout, B, Hd, Wd)
             L["wg2d"] = Wgrad2dDesc(B=B, H=Hd, W_=Wd, PHx=f0.PH, PWx=f0.PW, PHz=pph, PWz=ppw)
@@ -249,10 +268,10 @@ class HipUNetTrain:
         nz, Kc = _split_k(KH * Mrows, Cout, Mg)
         g_lo, g_hi = ph * Wg, ((KH - 1) * dh - ph) * Wg + 64
         a_ld = g_lo + nz * Kc + g_hi
-        L["XT"] = torch.zeros(Mrows, a_ld, dtype=torch.float16, device=dev)
-        L["dzT"] = torch.zeros(Cout, nz * Kc, dtype=torch.float16, device=dev)
+        L["XT"] = torch.zeros(pl + (Mrows, a_ld), dtype=torch.float16, device=dev)
+        L["dzT"] = torch.zeros(pl + (Cout, nz * Kc), dtype=torch.float16, device=dev)
         L["wpart"] = torch.empty(nz, KH, Mrows, Cout, dtype=torch.float32, device=dev)
-        L["wg"] = _SplitKGemm(Mrows, Cout, Kc, nz, a_ld, g_lo - ph * Wg, nz * Kc, dev, groups=KH, group_off=dh * Wg)
+        L["wg"] = _SplitKGemm(Mrows, Cout, Kc, nz, a_ld, g_lo - ph * Wg, nz * Kc, dev, groups=KH, group_off=dh * Wg, split=sp)
         tds, r0 = [], 0
         for s in srcs:
             f = m[s]
@@ -269,7 +288,8 @@ class HipUNetTrain:
         return L
 
     def _plan_up(self, name, src: G.FMap, dst: G.FMap, gsrc: G.FMap, gdst: G.FMap, stride, B) -> dict:
-        dev, p = self.dev, self.p
+        dev, p, sp = self.dev, self.p, self.split
+        pl = (2,) if sp else ()
         sh, sw = stride
         Cin, Cout = p[name + ".weight"].shape[:2]
         L = dict(kind="up", name=name, stride=stride, src=src, dst=dst, gsrc=gsrc, gdst=gdst, Cin=Cin, Cout=Cout)
@@ -280,10 +300,10 @@ class HipUNetTrain:
         Mg = B * Hg * Wg
         N = sh * sw * Cout
         nz, Kc = _split_k(Cin, N, Mg)
-        L["XT"] = torch.zeros(Cin, nz * Kc + 64, dtype=torch.float16, device=dev)
-        L["GT"] = torch.zeros(N, nz * Kc, dtype=torch.float16, device=dev)
+        L["XT"] = torch.zeros(pl + (Cin, nz * Kc + 64), dtype=torch.float16, device=dev)
+        L["GT"] = torch.zeros(pl + (N, nz * Kc), dtype=torch.float16, device=dev)
         L["wpart"] = torch.empty(nz, Cin, N, dtype=torch.float32, device=dev)
-        L["wg"] = _SplitKGemm(Cin, N, Kc, nz, nz * Kc + 64, 0, nz * Kc, dev)
+        L["wg"] = _SplitKGemm(Cin, N, Kc, nz, nz * Kc + 64, 0, nz * Kc, dev, split=sp)
         L["x_tr"] = TransposeDesc(B=B, Hg=Hg, Wg=Wg, GH=0, GW=0, H=src.H, W=src.W, Hs=src.H, Ws=src.W, PHs=src.PH, PWs=src.PW,
                                   Cs=src.C, c0=0, nC=Cin, sy=1, sx=1, ntap=1, ld=nz * Kc + 64, col0=0, rpt=Cin, r0=0)
         td = TransposeDesc(B=B, Hg=Hg, Wg=Wg, GH=0, GW=0, H=src.H, W=src.W, Hs=gdst.H, Ws=gdst.W, PHs=gdst.PH, PWs=gdst.PW,
@@ -299,7 +319,7 @@ class HipUNetTrain:
         lib, p, st = _lib.lib(), self.p, _st()
         Cn = zmap.C
         gm = _geom(zmap)
-        _lib.check(lib.advh_bn_stats(zmap.t.data_ptr(), C.byref(gm), ws["partial"].data_ptr(), ws["sums"].data_ptr(), st), "advh_bn_stats")
+        self._bn_stats(zmap, ws)
         n = float(zmap.B * zmap.H * zmap.W)
         gamma, beta = p[L["bname"] + ".weight"].detach(), p[L["bname"] + ".bias"].detach()
         rm, rv, nb = (p.get(L["bname"] + sfx) for sfx in (".running_mean", ".running_var", ".num_batches_tracked"))
@@ -311,7 +331,20 @@ class HipUNetTrain:
         _lib.check(lib.advh_bn_coef(ws["sums"].data_ptr(), gamma.data_ptr(), beta.data_ptr(), Cn, n, BN_EPS, BN_MOMENTUM,
                                     None if rm is None else rm.data_ptr(), None if rv is None else rv.data_ptr(), nbp,
                                     L["coef"].data_ptr(), st), "advh_bn_coef")
-        _lib.check(lib.advh_bn_apply(zmap.t.data_ptr(), C.byref(gm), L["coef"].data_ptr(), SLOPE, amap.t.data_ptr(), st), "advh_bn_apply")
+        if self.split:
+            _lib.check(lib.advh_bn_apply_split(zmap.t.data_ptr(), zmap.t.stride(0), C.byref(gm), L["coef"].data_ptr(), SLOPE, amap.t.data_ptr(),
+                                               amap.t.stride(0), st), "advh_bn_apply_split")
+        else:
+            _lib.check(lib.advh_bn_apply(zmap.t.data_ptr(), C.byref(gm), L["coef"].data_ptr(), SLOPE, amap.t.data_ptr(), st), "advh_bn_apply")
+
+    def _bn_stats(self, fmap: G.FMap, ws):
+        """per-channel (sum, sum of squares) of a map's interior -> ws["sums"]"""
+        lib, st, gm = _lib.lib(), _st(), _geom(fmap)
+        if self.split:
+            _lib.check(lib.advh_bn_stats_split(fmap.t.data_ptr(), fmap.t.stride(0), C.byref(gm), ws["partial"].data_ptr(),
+                                               ws["sums"].data_ptr(), st), "advh_bn_stats_split")
+        else:
+            _lib.check(lib.advh_bn_stats(fmap.t.data_ptr(), C.byref(gm), ws["partial"].data_ptr(), ws["sums"].data_ptr(), st), "advh_bn_stats")
 
     def forward(self, mag: torch.Tensor, H: int = 512, W: Optional[int] = None) -> torch.Tensor:
         if mag.dim() != 3 or mag.dtype != torch.float32 or not mag.is_cuda:
@@ -322,9 +355,13 @@ class HipUNetTrain:
         if H > Fq or W > Tq:
             raise ValueError("crop exceeds the spectrogram")
         ws = self._workspace(B, H, W)
-        m, z, lib, p, st = ws["maps"], ws["z"], _lib.lib(), self.p, _st()
+        m, z, lib, p, st, sp = ws["maps"], ws["z"], _lib.lib(), self.p, _st(), self.split
         u1 = m["u1"]
-        _lib.check(lib.advh_unet_pack_x(mag.data_ptr(), Fq, Tq, B, H, W, u1.t.data_ptr(), u1.C, 32, u1.PH, u1.PW, st), "advh_unet_pack_x")
+        if sp:
+            _lib.check(lib.advh_unet_pack_x_split(mag.data_ptr(), Fq, Tq, B, H, W, u1.t.data_ptr(), u1.t.stride(0), u1.C, 32, u1.PH, u1.PW, st),
+                       "advh_unet_pack_x_split")
+        else:
+            _lib.check(lib.advh_unet_pack_x(mag.data_ptr(), Fq, Tq, B, H, W, u1.t.data_ptr(), u1.C, 32, u1.PH, u1.PW, st), "advh_unet_pack_x")
         for L in ws["layers"]:
             if L["kind"] == "up":
                 w = p[L["name"] + ".weight"].detach()
@@ -337,8 +374,12 @@ class HipUNetTrain:
                 sw_ = p[L["cname"] + ".weight"].detach().reshape(32, 15).contiguous()
                 sb_ = p[L["cname"] + ".bias"].detach().contiguous()
                 L["keep"] = (sw_, sb_)
-                _lib.check(lib.advh_unet_stem(mag.data_ptr(), Fq, Tq, B, H, W, sw_.data_ptr(), sb_.data_ptr(), z[dst].t.data_ptr(),
-                                              z[dst].PH, z[dst].PW, 1.0, st), "advh_unet_stem")
+                if sp:
+                    _lib.check(lib.advh_unet_stem_split(mag.data_ptr(), Fq, Tq, B, H, W, sw_.data_ptr(), sb_.data_ptr(), z[dst].t.data_ptr(),
+                                                        z[dst].t.stride(0), z[dst].PH, z[dst].PW, 1.0, st), "advh_unet_stem_split")
+                else:
+                    _lib.check(lib.advh_unet_stem(mag.data_ptr(), Fq, Tq, B, H, W, sw_.data_ptr(), sb_.data_ptr(), z[dst].t.data_ptr(),
+                                                  z[dst].PH, z[dst].PW, 1.0, st), "advh_unet_stem")
             else:
                 L["fwd"].load_weights(_conv_w2(p[L["cname"] + ".weight"].detach(), L["splits"]), p[L["cname"] + ".bias"].detach())
                 srcs = L["srcs"]
@@ -347,32 +388,46 @@ class HipUNetTrain:
         y1 = m["y1"]
         hw = p["mask_head.0.weight"].detach().reshape(32).contiguous()
         hb = float(p["mask_head.0.bias"].detach().reshape(-1)[0])
-        _lib.check(lib.advh_unet_head(y1.t.data_ptr(), B, H, W, y1.PH, y1.PW, hw.data_ptr(), hb, ws["mask"].data_ptr(),
-                                      ws["logits"].data_ptr(), st), "advh_unet_head")
+        if sp:
+            _lib.check(lib.advh_unet_head_split(y1.t.data_ptr(), y1.t.stride(0), B, H, W, y1.PH, y1.PW, hw.data_ptr(), hb, ws["mask"].data_ptr(),
+                                                ws["logits"].data_ptr(), st), "advh_unet_head_split")
+        else:
+            _lib.check(lib.advh_unet_head(y1.t.data_ptr(), B, H, W, y1.PH, y1.PW, hw.data_ptr(), hb, ws["mask"].data_ptr(),
+                                          ws["logits"].data_ptr(), st), "advh_unet_head")
         self._last = (mag, B, Fq, Tq, H, W, hw)
         self.generation += 1
         return ws["mask"].clone()
 
     # ------------------------------------------------------------------------------------------ backward
     def _tr(self, src_t: torch.Tensor, dst: torch.Tensor, td: TransposeDesc):
+        if self.split:                                     # a transpose moves elements: once per plane
+            for pl in range(2):
+                _lib.check(_lib.lib().advh_transpose_gather(src_t[pl].data_ptr(), dst[pl].data_ptr(), C.byref(td), _st()), "advh_transpose_gather")
+            return
         _lib.check(_lib.lib().advh_transpose_gather(src_t.data_ptr(), dst.data_ptr(), C.byref(td), _st()), "advh_transpose_gather")
 
     def backward(self, dmask: torch.Tensor) -> Dict[str, torch.Tensor]:
         """``dmask [B, H, W]`` = dL/d mask of the last ``forward`` -> fp32 gradients of every trainable parameter."""
         mag, B, Fq, Tq, H, W, hw = self._last
         ws = self._workspace(B, H, W)
-        m, z, g, lib, p, st = ws["maps"], ws["z"], ws["g"], _lib.lib(), self.p, _st()
+        m, z, g, lib, p, st, sp = ws["maps"], ws["z"], ws["g"], _lib.lib(), self.p, _st(), self.split
         dmask = dmask.to(self.dev, torch.float32).contiguous()
         assert dmask.shape == (B, H, W)
         peak = float((dmask.abs().max() * 0.25 * hw.abs().max()).item())
         S = 2.0 ** max(-24, min(24, math.floor(math.log2(64.0 / peak)))) if peak > 0 and math.isfinite(peak) else 1.0
         grads: Dict[str, torch.Tensor] = {}
         y1, gy1 = m["y1"], g["y1"]
-        _lib.check(lib.advh_unet_head_bwd(dmask.data_ptr(), ws["mask"].data_ptr(), hw.data_ptr(), S, B * H * W, ws["dlogit"].data_ptr(),
-                                          gy1.t.data_ptr(), int(gy1.t.dtype == torch.float32), st), "advh_unet_head_bwd")
         dw33 = torch.empty(64, dtype=torch.float32, device=self.dev)
-        _lib.check(lib.advh_unet_head_wgrad(ws["dlogit"].data_ptr(), y1.t.data_ptr(), B * H * W, ws["partial"].data_ptr(),
-                                            dw33.data_ptr(), st), "advh_unet_head_wgrad")
+        if sp:
+            _lib.check(lib.advh_unet_head_bwd_split(dmask.data_ptr(), ws["mask"].data_ptr(), hw.data_ptr(), S, B * H * W, ws["dlogit"].data_ptr(),
+                                                    gy1.t.data_ptr(), gy1.t.stride(0), st), "advh_unet_head_bwd_split")
+            _lib.check(lib.advh_unet_head_wgrad_split(ws["dlogit"].data_ptr(), y1.t.data_ptr(), y1.t.stride(0), B * H * W,
+                                                      ws["partial"].data_ptr(), dw33.data_ptr(), st), "advh_unet_head_wgrad_split")
+        else:
+            _lib.check(lib.advh_unet_head_bwd(dmask.data_ptr(), ws["mask"].data_ptr(), hw.data_ptr(), S, B * H * W, ws["dlogit"].data_ptr(),
+                                              gy1.t.data_ptr(), int(gy1.t.dtype == torch.float32), st), "advh_unet_head_bwd")
+            _lib.check(lib.advh_unet_head_wgrad(ws["dlogit"].data_ptr(), y1.t.data_ptr(), B * H * W, ws["partial"].data_ptr(),
+                                                dw33.data_ptr(), st), "advh_unet_head_wgrad")
         grads["mask_head.0.weight"] = dw33[:32].clone().view(1, 32, 1, 1)
         grads["mask_head.0.bias"] = dw33[32:33].clone()
         fresh = set()                                            # skip maps whose gradient has been written once already
@@ -385,8 +440,12 @@ class HipUNetTrain:
             gm = _geom(z[dst])
             coef = L["coef"]
             g32 = int(g[dst].t.dtype == torch.float32)
-            _lib.check(lib.advh_bn_bwd_sums(z[dst].t.data_ptr(), g[dst].t.data_ptr(), g32, C.byref(gm), coef.data_ptr(), SLOPE,
-                                            ws["partial"].data_ptr(), ws["sums"].data_ptr(), st), "advh_bn_bwd_sums")
+            if sp:
+                _lib.check(lib.advh_bn_bwd_sums_split(z[dst].t.data_ptr(), z[dst].t.stride(0), g[dst].t.data_ptr(), g[dst].t.stride(0), C.byref(gm),
+                                                      coef.data_ptr(), SLOPE, ws["partial"].data_ptr(), ws["sums"].data_ptr(), st), "advh_bn_bwd_sums_split")
+            else:
+                _lib.check(lib.advh_bn_bwd_sums(z[dst].t.data_ptr(), g[dst].t.data_ptr(), g32, C.byref(gm), coef.data_ptr(), SLOPE,
+                                                ws["partial"].data_ptr(), ws["sums"].data_ptr(), st), "advh_bn_bwd_sums")
             dgam, dbet = (torch.empty(Cn, dtype=torch.float32, device=self.dev) for _ in range(2))
             coef_b = L["coef_b"]
             _lib.check(lib.advh_bn_bwd_coef(ws["sums"].data_ptr(), coef.data_ptr(), Cn, n, 1.0 / S, coef_b.data_ptr(), dgam.data_ptr(),
@@ -394,14 +453,23 @@ class HipUNetTrain:
             grads[L["bname"] + ".weight"], grads[L["bname"] + ".bias"] = dgam, dbet
             dzm = L["dz"]
             sB, sH, sW, c0 = L["dz_strides"]
-            _lib.check(lib.advh_bn_bwd_apply(z[dst].t.data_ptr(), g[dst].t.data_ptr(), g32, C.byref(gm), coef.data_ptr(), coef_b.data_ptr(),
-                                             SLOPE, dzm.t.data_ptr(), sB, sH, sW, c0, st), "advh_bn_bwd_apply")
+            if sp:
+                _lib.check(lib.advh_bn_bwd_apply_split(z[dst].t.data_ptr(), z[dst].t.stride(0), g[dst].t.data_ptr(), g[dst].t.stride(0), C.byref(gm),
+                                                       coef.data_ptr(), coef_b.data_ptr(), SLOPE, dzm.t.data_ptr(), dzm.t.stride(0), sB, sH, sW, c0, st),
+                           "advh_bn_bwd_apply_split")
+            else:
+                _lib.check(lib.advh_bn_bwd_apply(z[dst].t.data_ptr(), g[dst].t.data_ptr(), g32, C.byref(gm), coef.data_ptr(), coef_b.data_ptr(),
+                                                 SLOPE, dzm.t.data_ptr(), sB, sH, sW, c0, st), "advh_bn_bwd_apply")
             grads[L["cname"] + ".bias"] = torch.zeros_like(p[L["cname"] + ".bias"])    # exactly zero before a batch-stat BatchNorm
             w = p[L["cname"] + ".weight"].detach()
             if L["srcs"] == ["mag"]:
                 dw = torch.empty(32, 15, dtype=torch.float32, device=self.dev)
-                _lib.check(lib.advh_unet_stem_wgrad(dzm.t.data_ptr(), Fq, Tq, B, H, W, mag.data_ptr(), dzm.PH, dzm.PW,
-                                                    L["stem_part"].data_ptr(), dw.data_ptr(), st), "advh_unet_stem_wgrad")
+                if sp:
+                    _lib.check(lib.advh_unet_stem_wgrad_split(dzm.t.data_ptr(), dzm.t.stride(0), Fq, Tq, B, H, W, mag.data_ptr(), dzm.PH, dzm.PW,
+                                                              L["stem_part"].data_ptr(), dw.data_ptr(), st), "advh_unet_stem_wgrad_split")
+                else:
+                    _lib.check(lib.advh_unet_stem_wgrad(dzm.t.data_ptr(), Fq, Tq, B, H, W, mag.data_ptr(), dzm.PH, dzm.PW,
+                                                        L["stem_part"].data_ptr(), dw.data_ptr(), st), "advh_unet_stem_wgrad")
                 grads[L["cname"] + ".weight"] = (dw / S).view(32, 1, 5, 3)
                 continue
             KH, KW = L["k"]
@@ -444,8 +512,7 @@ class HipUNetTrain:
         lib, p, st = _lib.lib(), self.p, _st()
         name, (sh, sw), Cin, Cout = L["name"], L["stride"], L["Cin"], L["Cout"]
         gd, gs = L["gdst"], L["gsrc"]
-        gm = _geom(gd)
-        _lib.check(lib.advh_bn_stats(gd.t.data_ptr(), C.byref(gm), ws["partial"].data_ptr(), ws["sums"].data_ptr(), st), "advh_bn_stats")
+        self._bn_stats(gd, ws)
         grads[name + ".bias"] = ws["sums"][:Cout].clone() / S
         self._tr(L["src"].t, L["XT"], L["x_tr"])
         self._tr(gd.t, L["GT"], L["g_tr"])

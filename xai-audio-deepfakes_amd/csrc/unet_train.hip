@@ -10,6 +10,7 @@
 #include <hip/hip_fp16.h>
 #include "addvisor_hip.h"
 #include "common.h"
+#include "device_math.h"
 
 namespace advh {
 
@@ -30,14 +31,13 @@ __device__ __forceinline__ bool interior(const MapGeom& g, long row, int& b, int
 // MODE 0: (sum z, sum z^2).  MODE 1 (BatchNorm backward): with y = scale*z + shift, dy^ = g * lrelu'(y),
 // z^ = (z - mean) * invstd: (sum dy^, sum dy^ z^).  coef = [scale | shift | mean | invstd] (4 x C floats).
 // One thread owns 8 channels of every (NPART * lanes_per_chunk)-th row.
-__device__ __forceinline__ void load_g8(const void* g, bool f32, long off, float (&o)[8]) {
+// fp32, fp16 (lo == 0) or a split-format plane pair (lo = distance to the lo plane; device_math.h)
+__device__ __forceinline__ void load_g8(const void* g, bool f32, long off, float (&o)[8], long lo = 0) {
     if (f32) {
         const float4 a = *(const float4*)((const float*)g + off), b = *(const float4*)((const float*)g + off + 4);
         o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
     } else {
-        const f16x8 v = *(const f16x8*)((const _Float16*)g + off);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = (float)v[j];
+        load_h_rt<8>((const _Float16*)g, off, lo, o);
     }
 }
 
@@ -46,7 +46,7 @@ __device__ __forceinline__ void load_g8(const void* g, bool f32, long off, float
 template <int MODE>
 __global__ __launch_bounds__(256) void bn_partial_kernel(const _Float16* __restrict__ z, const void* __restrict__ g, bool g_f32,
                                                          const float* __restrict__ coef, float slope, MapGeom gm,
-                                                         float* __restrict__ partial /*[NPART][2][C]*/) {
+                                                         float* __restrict__ partial /*[NPART][2][C]*/, long z_lo, long g_lo) {
     __shared__ float red[256 * 16];
     const int CH = gm.C / 8, tid = threadIdx.x;
     const int ch = tid % CH, rl = tid / CH, RL = 256 / CH;       // CH in {4, 8, 16, 32, 64}
@@ -64,16 +64,17 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const _Float16* __restr
         for (long row = (long)blockIdx.x * RL + rl; row < rows; row += (long)gridDim.x * RL) {
             int b, h, w;
             if (!interior(gm, row, b, h, w)) continue;
-            const f16x8 zv = *(const f16x8*)(z + row * gm.C + ch * 8);
+            float zv[8];
+            load_h_rt<8>(z, row * gm.C + ch * 8, z_lo, zv);
             if (MODE == 0) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { float v = (float)zv[j]; s1[j] += v; s2[j] = fmaf(v, v, s2[j]); }
+                for (int j = 0; j < 8; ++j) { float v = zv[j]; s1[j] += v; s2[j] = fmaf(v, v, s2[j]); }
             } else {
                 float gv[8];
-                load_g8(g, g_f32, row * gm.C + ch * 8, gv);
+                load_g8(g, g_f32, row * gm.C + ch * 8, gv, g_lo);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    float zz = (float)zv[j], y = fmaf(sc[j], zz, sh[j]);
+                    float zz = zv[j], y = fmaf(sc[j], zz, sh[j]);
                     float d = gv[j] * (y > 0.f ? 1.f : slope);
                     s1[j] += d;
                     s2[j] = fmaf(d, (zz - mu[j]) * is[j], s2[j]);
@@ -138,7 +139,7 @@ template <int BWD>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const _Float16* __restrict__ z, const void* __restrict__ g, bool g_f32,
                                                        const float* __restrict__ coef, const float* __restrict__ coef_b,
                                                        float slope, MapGeom gm, _Float16* __restrict__ dst, long d_sB, long d_sH,
-                                                       long d_sW, long d_c0) {
+                                                       long d_sW, long d_c0, long z_lo, long g_lo, long d_lo) {
     const int CH = gm.C / 8;
     const long total = (long)gm.B * gm.Hp * gm.Wp * CH;
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -147,28 +148,28 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const _Float16* __restric
     const long row = i / CH;
     int b, h, w;
     if (!interior(gm, row, b, h, w)) return;
-    const f16x8 zv = *(const f16x8*)(z + row * gm.C + ch * 8);
-    f16x8 o;
+    float zv[8], o[8];
+    load_h_rt<8>(z, row * gm.C + ch * 8, z_lo, zv);
     if (!BWD) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int c = ch * 8 + j;
-            float y = fmaf(coef[c], (float)zv[j], coef[gm.C + c]);
-            o[j] = (_Float16)(y > 0.f ? y : slope * y);
+            float y = fmaf(coef[c], zv[j], coef[gm.C + c]);
+            o[j] = y > 0.f ? y : slope * y;
         }
     } else {
         float gv[8];
-        load_g8(g, g_f32, row * gm.C + ch * 8, gv);
+        load_g8(g, g_f32, row * gm.C + ch * 8, gv, g_lo);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int c = ch * 8 + j;
-            float zz = (float)zv[j], y = fmaf(coef[c], zz, coef[gm.C + c]);
+            float zz = zv[j], y = fmaf(coef[c], zz, coef[gm.C + c]);
             float d = gv[j] * (y > 0.f ? 1.f : slope);
             float zh = (zz - coef[2 * gm.C + c]) * coef[3 * gm.C + c];
-            o[j] = (_Float16)(coef_b[c] * (d - coef_b[gm.C + c] - zh * coef_b[2 * gm.C + c]));
+            o[j] = coef_b[c] * (d - coef_b[gm.C + c] - zh * coef_b[2 * gm.C + c]);
         }
     }
-    *(f16x8*)(dst + d_c0 + (long)b * d_sB + (long)(h - gm.PH) * d_sH + (long)(w - gm.PW) * d_sW + ch * 8) = o;
+    store_h_rt<8>(dst, d_c0 + (long)b * d_sB + (long)(h - gm.PH) * d_sH + (long)(w - gm.PW) * d_sW + ch * 8, d_lo, o);
 }
 
 // Operand transpose of the weight-gradient GEMM.  dst[(t*nC + c)][col0 + p] = src[b][PHs + y][PWs + x][c0 + c] with
@@ -238,7 +239,7 @@ __global__ __launch_bounds__(256) void transpose_gather_kernel(const _Float16* _
 // `scale`); dlogit itself is stored (fp32) for the weight / bias sums.
 __global__ __launch_bounds__(256) void unet_head_bwd_kernel(const float* __restrict__ dmask, const float* __restrict__ mask,
                                                             const float* __restrict__ w32, float scale, long total,
-                                                            float* __restrict__ dlogit, void* __restrict__ dy1, bool dy_f32) {
+                                                            float* __restrict__ dlogit, void* __restrict__ dy1, bool dy_f32, long dy_lo) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
     const float m = mask[i], d = dmask[i] * m * (1.f - m);
@@ -251,10 +252,10 @@ __global__ __launch_bounds__(256) void unet_head_bwd_kernel(const float* __restr
     } else {
 #pragma unroll
         for (int c8 = 0; c8 < 4; ++c8) {
-            f16x8 v;
+            float v[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = (_Float16)(ds * w32[c8 * 8 + j]);
-            *(f16x8*)((_Float16*)dy1 + i * 32 + c8 * 8) = v;
+            for (int j = 0; j < 8; ++j) v[j] = ds * w32[c8 * 8 + j];
+            store_h_rt<8>((_Float16*)dy1, i * 32 + c8 * 8, dy_lo, v);
         }
     }
 }
@@ -262,7 +263,7 @@ __global__ __launch_bounds__(256) void unet_head_bwd_kernel(const float* __restr
 // weight / bias gradient of the 1x1 mask head: dw[c] = sum_i dlogit[i] * y1[i][c] (c < 32), dw[32] = sum_i dlogit[i].
 // Thread = (8-channel chunk, row lane); partial [NPART][64] (33 used), reduced by bn_reduce_kernel with C = 32.
 __global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict__ dlogit, const _Float16* __restrict__ y1, long total,
-                                                         float* __restrict__ partial) {
+                                                         float* __restrict__ partial, long y_lo) {
     __shared__ float red[64][36];
     const int ch = threadIdx.x & 3, rl = threadIdx.x >> 2;
     float acc[8], sd = 0.f;
@@ -270,9 +271,10 @@ __global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict
     for (int j = 0; j < 8; ++j) acc[j] = 0.f;
     for (long i = (long)blockIdx.x * 64 + rl; i < total; i += (long)gridDim.x * 64) {
         const float d = dlogit[i];
-        const f16x8 v = *(const f16x8*)(y1 + i * 32 + ch * 8);
+        float v[8];
+        load_h_rt<8>(y1, i * 32 + ch * 8, y_lo, v);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] = fmaf(d, (float)v[j], acc[j]);
+        for (int j = 0; j < 8; ++j) acc[j] = fmaf(d, v[j], acc[j]);
         if (ch == 0) sd += d;
     }
 #pragma unroll
@@ -290,7 +292,8 @@ __global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict
 // dW[co][kh*3+kw] = sum_p dz[p][co] * mag[b][2ho+kh-2][w+kw-1].  Thread = (co, position lane); the 15 magnitudes of a
 // position are the same for the 32 channel threads (broadcast loads).  Two-stage deterministic reduction.
 __global__ __launch_bounds__(256) void stem_wgrad_kernel(const _Float16* __restrict__ dz, const float* __restrict__ mag, int Fq, int Tq,
-                                                         int B, int H, int W, int PH, int PW, float* __restrict__ partial /*[NPART][480]*/) {
+                                                         int B, int H, int W, int PH, int PW, float* __restrict__ partial /*[NPART][480]*/,
+                                                         long dz_lo) {
     __shared__ float red[8][480];
     const int co = threadIdx.x & 31, pl = threadIdx.x >> 5, Ho = H / 2;
     const long total = (long)B * Ho * W;
@@ -301,7 +304,8 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const _Float16* __restr
         const int w = (int)(i % W);
         const long r = i / W;
         const int ho = (int)(r % Ho), b = (int)(r / Ho);
-        const float d = (float)dz[(((long)b * (Ho + 2 * PH) + ho + PH) * (W + 2 * PW) + w + PW) * 32 + co];
+        const long di = (((long)b * (Ho + 2 * PH) + ho + PH) * (W + 2 * PW) + w + PW) * 32 + co;
+        const float d = dz_lo ? join_f32(dz[di], dz[di + dz_lo]) : (float)dz[di];
 #pragma unroll
         for (int kh = 0; kh < 5; ++kh)
 #pragma unroll
@@ -325,22 +329,39 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const _Float16* __restr
 
 using namespace advh;
 
-extern "C" int advh_unet_head_wgrad(const float* dlogit, const void* y1, int64_t total, float* partial, float* dw33,
-                                    advh_stream_t stream) {
+static int head_wgrad_launch(const float* dlogit, const void* y1, long y_lo, int64_t total, float* partial, float* dw33, advh_stream_t stream) {
     if (!dlogit || !y1 || !partial || !dw33 || total <= 0) return ADVH_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(head_wgrad_kernel, dim3(NPART), dim3(256), 0, s, dlogit, (const _Float16*)y1, (long)total, partial);
+    hipLaunchKernelGGL(head_wgrad_kernel, dim3(NPART), dim3(256), 0, s, dlogit, (const _Float16*)y1, (long)total, partial, y_lo);
     hipLaunchKernelGGL(bn_reduce_kernel, dim3(16), dim3(256), 0, s, partial, NPART, 32, dw33);    // 64 outputs, 33 used
     return ADVH_LAUNCH_CHECK();
 }
+extern "C" int advh_unet_head_wgrad(const float* dlogit, const void* y1, int64_t total, float* partial, float* dw33,
+                                    advh_stream_t stream) {
+    return head_wgrad_launch(dlogit, y1, 0, total, partial, dw33, stream);
+}
+extern "C" int advh_unet_head_wgrad_split(const float* dlogit, const void* y1, int64_t y_lo, int64_t total, float* partial, float* dw33,
+                                          advh_stream_t stream) {
+    if (y_lo <= 0 || y_lo % 8) return ADVH_EINVAL;
+    return head_wgrad_launch(dlogit, y1, y_lo, total, partial, dw33, stream);
+}
 
-extern "C" int advh_unet_stem_wgrad(const void* dz, int Fq, int Tq, int B, int H, int W, const float* mag, int PH, int PW,
-                                    float* partial, float* dw, advh_stream_t stream) {
+static int stem_wgrad_launch(const void* dz, long dz_lo, int Fq, int Tq, int B, int H, int W, const float* mag, int PH, int PW,
+                             float* partial, float* dw, advh_stream_t stream) {
     if (!dz || !mag || !partial || !dw || B <= 0 || H <= 0 || (H & 1) || W <= 0 || H > Fq || W > Tq || PH < 0 || PW < 0) return ADVH_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(stem_wgrad_kernel, dim3(NPART), dim3(256), 0, s, (const _Float16*)dz, mag, Fq, Tq, B, H, W, PH, PW, partial);
+    hipLaunchKernelGGL(stem_wgrad_kernel, dim3(NPART), dim3(256), 0, s, (const _Float16*)dz, mag, Fq, Tq, B, H, W, PH, PW, partial, dz_lo);
     hipLaunchKernelGGL(bn_reduce_kernel, dim3(120), dim3(256), 0, s, partial, NPART, 240, dw);
     return ADVH_LAUNCH_CHECK();
+}
+extern "C" int advh_unet_stem_wgrad(const void* dz, int Fq, int Tq, int B, int H, int W, const float* mag, int PH, int PW,
+                                    float* partial, float* dw, advh_stream_t stream) {
+    return stem_wgrad_launch(dz, 0, Fq, Tq, B, H, W, mag, PH, PW, partial, dw, stream);
+}
+extern "C" int advh_unet_stem_wgrad_split(const void* dz, int64_t dz_lo, int Fq, int Tq, int B, int H, int W, const float* mag, int PH,
+                                          int PW, float* partial, float* dw, advh_stream_t stream) {
+    if (dz_lo <= 0) return ADVH_EINVAL;
+    return stem_wgrad_launch(dz, dz_lo, Fq, Tq, B, H, W, mag, PH, PW, partial, dw, stream);
 }
 
 static bool geom_ok(const advh_map_geom* g) {
@@ -350,13 +371,20 @@ static MapGeom mk(const advh_map_geom* g) { return MapGeom{g->B, g->H + 2 * g->P
 
 extern "C" int advh_bn_partial_count(void) { return NPART; }
 
-extern "C" int advh_bn_stats(const void* z, const advh_map_geom* g, float* partial, float* sums, advh_stream_t stream) {
+static int bn_stats_launch(const void* z, long z_lo, const advh_map_geom* g, float* partial, float* sums, advh_stream_t stream) {
     if (!z || !partial || !sums || !geom_ok(g)) return ADVH_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(NPART), dim3(256), 0, s, (const _Float16*)z, (const void*)nullptr, false,
-                       (const float*)nullptr, 0.f, mk(g), partial);
+                       (const float*)nullptr, 0.f, mk(g), partial, z_lo, 0L);
     hipLaunchKernelGGL(bn_reduce_kernel, dim3((2 * g->C + 3) / 4), dim3(256), 0, s, partial, NPART, g->C, sums);
     return ADVH_LAUNCH_CHECK();
+}
+extern "C" int advh_bn_stats(const void* z, const advh_map_geom* g, float* partial, float* sums, advh_stream_t stream) {
+    return bn_stats_launch(z, 0, g, partial, sums, stream);
+}
+extern "C" int advh_bn_stats_split(const void* z, int64_t z_lo, const advh_map_geom* g, float* partial, float* sums, advh_stream_t stream) {
+    if (z_lo <= 0 || z_lo % 8) return ADVH_EINVAL;
+    return bn_stats_launch(z, z_lo, g, partial, sums, stream);
 }
 
 extern "C" int advh_bn_coef(const float* sums, const float* gamma, const float* beta, int C, float n, float eps, float momentum,
@@ -375,37 +403,66 @@ extern "C" int advh_bn_bwd_coef(const float* sums, const float* coef, int C, flo
     return ADVH_LAUNCH_CHECK();
 }
 
-extern "C" int advh_bn_apply(const void* z, const advh_map_geom* g, const float* coef, float slope, void* a, advh_stream_t stream) {
+static int bn_apply_launch(const void* z, long z_lo, const advh_map_geom* g, const float* coef, float slope, void* a, long a_lo,
+                           advh_stream_t stream) {
     if (!z || !a || !coef || !geom_ok(g)) return ADVH_EINVAL;
     MapGeom m = mk(g);
     const long total = (long)m.B * m.Hp * m.Wp * (m.C / 8);
     hipLaunchKernelGGL(bn_apply_kernel<0>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        (const _Float16*)z, (const void*)nullptr, false, coef, (const float*)nullptr, slope, m, (_Float16*)a,
-                       (long)m.Hp * m.Wp * m.C, (long)m.Wp * m.C, (long)m.C, ((long)m.PH * m.Wp + m.PW) * m.C);
+                       (long)m.Hp * m.Wp * m.C, (long)m.Wp * m.C, (long)m.C, ((long)m.PH * m.Wp + m.PW) * m.C, z_lo, 0L, a_lo);
     return ADVH_LAUNCH_CHECK();
 }
+extern "C" int advh_bn_apply(const void* z, const advh_map_geom* g, const float* coef, float slope, void* a, advh_stream_t stream) {
+    return bn_apply_launch(z, 0, g, coef, slope, a, 0, stream);
+}
+extern "C" int advh_bn_apply_split(const void* z, int64_t z_lo, const advh_map_geom* g, const float* coef, float slope, void* a,
+                                   int64_t a_lo, advh_stream_t stream) {
+    if (z_lo <= 0 || a_lo <= 0 || z_lo % 8 || a_lo % 8) return ADVH_EINVAL;
+    return bn_apply_launch(z, z_lo, g, coef, slope, a, a_lo, stream);
+}
 
-extern "C" int advh_bn_bwd_sums(const void* z, const void* g_a, int g_f32, const advh_map_geom* g, const float* coef, float slope,
-                                float* partial, float* sums, advh_stream_t stream) {
+static int bn_bwd_sums_launch(const void* z, long z_lo, const void* g_a, int g_f32, long g_lo, const advh_map_geom* g, const float* coef,
+                              float slope, float* partial, float* sums, advh_stream_t stream) {
     if (!z || !g_a || !coef || !partial || !sums || !geom_ok(g)) return ADVH_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(bn_partial_kernel<1>, dim3(NPART), dim3(256), 0, s, (const _Float16*)z, g_a, g_f32 != 0, coef, slope,
-                       mk(g), partial);
+                       mk(g), partial, z_lo, g_lo);
     hipLaunchKernelGGL(bn_reduce_kernel, dim3((2 * g->C + 3) / 4), dim3(256), 0, s, partial, NPART, g->C, sums);
     return ADVH_LAUNCH_CHECK();
 }
+extern "C" int advh_bn_bwd_sums(const void* z, const void* g_a, int g_f32, const advh_map_geom* g, const float* coef, float slope,
+                                float* partial, float* sums, advh_stream_t stream) {
+    return bn_bwd_sums_launch(z, 0, g_a, g_f32, 0, g, coef, slope, partial, sums, stream);
+}
+extern "C" int advh_bn_bwd_sums_split(const void* z, int64_t z_lo, const void* g_a, int64_t g_lo, const advh_map_geom* g, const float* coef,
+                                      float slope, float* partial, float* sums, advh_stream_t stream) {
+    if (z_lo <= 0 || g_lo <= 0 || z_lo % 8 || g_lo % 8) return ADVH_EINVAL;
+    return bn_bwd_sums_launch(z, z_lo, g_a, 0, g_lo, g, coef, slope, partial, sums, stream);
+}
 
-extern "C" int advh_bn_bwd_apply(const void* z, const void* g_a, int g_f32, const advh_map_geom* g, const float* coef, const float* coef_b,
-                                 float slope, void* dz, int64_t d_sB, int64_t d_sH, int64_t d_sW, int64_t d_c0,
-                                 advh_stream_t stream) {
+static int bn_bwd_apply_launch(const void* z, long z_lo, const void* g_a, int g_f32, long g_lo, const advh_map_geom* g, const float* coef,
+                               const float* coef_b, float slope, void* dz, long dz_lo, int64_t d_sB, int64_t d_sH, int64_t d_sW,
+                               int64_t d_c0, advh_stream_t stream) {
     if (!z || !g_a || !dz || !coef || !coef_b || !geom_ok(g)) return ADVH_EINVAL;
     if ((d_sB | d_sH | d_sW | d_c0) & 7) return ADVH_EINVAL;
     MapGeom m = mk(g);
     const long total = (long)m.B * m.Hp * m.Wp * (m.C / 8);
     hipLaunchKernelGGL(bn_apply_kernel<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        (const _Float16*)z, g_a, g_f32 != 0, coef, coef_b, slope, m, (_Float16*)dz, (long)d_sB, (long)d_sH,
-                       (long)d_sW, (long)d_c0);
+                       (long)d_sW, (long)d_c0, z_lo, g_lo, dz_lo);
     return ADVH_LAUNCH_CHECK();
+}
+extern "C" int advh_bn_bwd_apply(const void* z, const void* g_a, int g_f32, const advh_map_geom* g, const float* coef, const float* coef_b,
+                                 float slope, void* dz, int64_t d_sB, int64_t d_sH, int64_t d_sW, int64_t d_c0,
+                                 advh_stream_t stream) {
+    return bn_bwd_apply_launch(z, 0, g_a, g_f32, 0, g, coef, coef_b, slope, dz, 0, d_sB, d_sH, d_sW, d_c0, stream);
+}
+extern "C" int advh_bn_bwd_apply_split(const void* z, int64_t z_lo, const void* g_a, int64_t g_lo, const advh_map_geom* g, const float* coef,
+                                       const float* coef_b, float slope, void* dz, int64_t dz_lo, int64_t d_sB, int64_t d_sH, int64_t d_sW,
+                                       int64_t d_c0, advh_stream_t stream) {
+    if (z_lo <= 0 || g_lo <= 0 || dz_lo <= 0 || z_lo % 8 || g_lo % 8 || dz_lo % 8) return ADVH_EINVAL;
+    return bn_bwd_apply_launch(z, z_lo, g_a, 0, g_lo, g, coef, coef_b, slope, dz, dz_lo, d_sB, d_sH, d_sW, d_c0, stream);
 }
 
 extern "C" int advh_transpose_gather(const void* src, void* dst, const advh_transpose_desc* d, advh_stream_t stream) {
@@ -427,10 +484,19 @@ extern "C" int advh_transpose_gather(const void* src, void* dst, const advh_tran
     return ADVH_LAUNCH_CHECK();
 }
 
-extern "C" int advh_unet_head_bwd(const float* dmask, const float* mask, const float* w32, float scale, int64_t total,
-                                  float* dlogit, void* dy1, int dy_f32, advh_stream_t stream) {
+static int head_bwd_launch(const float* dmask, const float* mask, const float* w32, float scale, int64_t total, float* dlogit, void* dy1,
+                           int dy_f32, long dy_lo, advh_stream_t stream) {
     if (!dmask || !mask || !w32 || !dlogit || !dy1 || total <= 0) return ADVH_EINVAL;
     hipLaunchKernelGGL(unet_head_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dmask,
-                       mask, w32, scale, (long)total, dlogit, dy1, dy_f32 != 0);
+                       mask, w32, scale, (long)total, dlogit, dy1, dy_f32 != 0, dy_lo);
     return ADVH_LAUNCH_CHECK();
+}
+extern "C" int advh_unet_head_bwd(const float* dmask, const float* mask, const float* w32, float scale, int64_t total,
+                                  float* dlogit, void* dy1, int dy_f32, advh_stream_t stream) {
+    return head_bwd_launch(dmask, mask, w32, scale, total, dlogit, dy1, dy_f32, 0, stream);
+}
+extern "C" int advh_unet_head_bwd_split(const float* dmask, const float* mask, const float* w32, float scale, int64_t total,
+                                        float* dlogit, void* dy1, int64_t dy_lo, advh_stream_t stream) {
+    if (dy_lo <= 0 || dy_lo % 8) return ADVH_EINVAL;
+    return head_bwd_launch(dmask, mask, w32, scale, total, dlogit, dy1, 0, dy_lo, stream);
 }

@@ -16,12 +16,18 @@ audio_processor = AudioProcessor()
 
 class LMACLoss(nn.Module):
     def __init__(self, reg_w_tv=0.00, loss_scale=4096.0):
-        """``loss_scale``: power-of-two scale of the fp16 gradients inside the frozen embedder's backward (backed off
-        automatically on overflow, addvisor_hip/lmac_loss.py); the reference's signature is ``LMACLoss(reg_w_tv=0.0)``."""
+        """``loss_scale``: initial power-of-two scale of the gradients inside the frozen embedder's backward (backed off on
+        overflow and kept, grown back after clean steps: addvisor_hip/lmac_loss.LossScaler); the reference's signature is
+        ``LMACLoss(reg_w_tv=0.0)``."""
         super().__init__()
         self.reg_w_tv = reg_w_tv
-        self.loss_scale = float(loss_scale)
+        from addvisor_hip.lmac_loss import LossScaler
+        self.scaler = LossScaler(float(loss_scale))
         self.w_raw = nn.Parameter(torch.tensor([3.0, 0.5, 3.0], requires_grad=True))     # loss_function.py:24
+
+    @property
+    def loss_scale(self) -> float:
+        return self.scaler.scale
 
     @property
     def w(self):
@@ -39,7 +45,7 @@ class LMACLoss(nn.Module):
         if torch.is_grad_enabled() and m.requires_grad:
             from addvisor_hip.lmac_loss import lmac_terms
             losses = lmac_terms(m, mag, ph, cp, _rt.hip_embedder_grad(), L, hop=ap.hop_length, win=ap.win_length,
-                                loss_scale=self.loss_scale)
+                                loss_scale=self.scaler)
         else:
             w_in, w_out = _ops.istft_masked(mag, ph, m.detach(), L, domain="linear", hop=ap.hop_length, win=ap.win_length)
             emb = _rt.hip_embedder()
