@@ -22,7 +22,7 @@ FLOPs of its launches / their device time, measured with HIP events recorded on 
 steps.  `cpu_baseline` times the CPU oracle (plain torch, the reference arithmetic) on a bounded sample of the same
 workload on this host's cores (rank 0, N = 1 only).  The default N = 1 invocation also measures BASELINE config 3
 (`"hifigan"`: HiFi-GAN V1, 256 x 251 mel frames), config 5's per-GPU share (`"ig"`: IntegratedGradients, 50 steps x
-16 clips, wav2vec2-large), the vocoder variant of the step (`"explain_vocoder"`) and one rank's data-set loop of config 4
+16 clips, wav2vec2-large, fp32-class gradient chain; the fp16 chain under its `"f16"` sub-key), the vocoder variant of the step (`"explain_vocoder"`) and one rank's data-set loop of config 4
 with the PCIe upload inside the timed region (`"dataset"`: 4 133 clips from pinned host memory, ragged last batch) and
 appends them as extra keys; `--workload hifigan|ig|dataset` runs one of them as the headline.
 """
@@ -139,7 +139,7 @@ def main():
     if args.workload == "hifigan":
         line = hifigan_line(ctx, bench_hifigan(ctx, args.batch if args.batch != BATCH else 256, args.steps, args.warmup))
     elif args.workload == "ig":
-        line = ig_line(ctx, bench_ig(ctx, 16, 64))
+        line = ig_line(ctx, bench_ig(ctx, 16, 64, args.precision))
     elif args.workload == "dataset":
         r = bench_dataset(ctx, args.precision)
         line = {"metric": "explanations/sec over a host-resident data set (PCIe upload included)", "value": r["value"], "unit": "explanations/s",
@@ -232,7 +232,7 @@ def gemm_roofline(G, precision, tuned=False):
             "gflop_per_launch": None if not n else round(flops / n / 1e9, 2)}
 
 
-def measured_traffic(kernel, precision):
+def measured_traffic(kernel, precision, batch=BATCH, streams=1):
     """HBM bytes per launch of `kernel`, measured NOW: two child runs of this script under `rocprofv3 --pmc` (FETCH_SIZE and
     WRITE_SIZE in separate passes with --kernel-trace only, as MI355X_MICROARCH.md's HBM section prescribes; FETCH_SIZE x2:
     gfx950 counts 128-byte requests as 64; both counters in KiB), started as child processes after the timed region (the
@@ -251,7 +251,7 @@ def measured_traffic(kernel, precision):
             d = os.path.join(tmp, counter)
             cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable,
                    os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extras", "--no-traffic",
-                   "--precision", precision]
+                   "--precision", precision, "--batch", str(batch), "--streams", str(streams)]      # the SAME workload as the timed run
             r = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600, env=dict(os.environ, TMPDIR="/tmp"))
             vals = []
             for fn in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
@@ -311,7 +311,7 @@ def explain_line(ctx):
     extras = world == 1 and not args.no_extras and not args.tune
     if rank == 0 and world == 1 and not args.no_traffic and not args.tune and head["roofline"]["launches"]:
         kern = head["roofline"]["kernel"]
-        nbytes, src = measured_traffic(kern, args.precision)
+        nbytes, src = measured_traffic(kern, args.precision, args.batch, args.streams)
         if nbytes is not None:
             line["roofline"]["traffic"], line["roofline"]["traffic_source"] = nbytes, src
         else:
@@ -439,9 +439,11 @@ def hifigan_line(ctx, r):
 
 
 # ------------------------------------------------------------------------------------------ BASELINE config 5
-def bench_ig(ctx, B, chunk):
+def bench_ig(ctx, B, chunk, precision="f32", both=True):
     """IntegratedGradients, n_steps = 50, wav2vec2-large, B clips = one GPU's share of config 5's batch of 128 over 8 GPUs;
-    path-batched forward + dgrad-only backward on the fp16 kernels."""
+    path-batched forward + dgrad-only backward.  Headline precision: the fp32-class chain (split-format activations and
+    gradients, three fp16 MFMAs per product, attention backward on the fp32 MFMA -- the reference differentiates with fp32
+    autograd, captum_saliency.py:131-135); the fp16-operand chain is timed too and reported under "f16"."""
     import torch
     from addvisor_hip import gemm as G, synthetic as syn
     from addvisor_hip.attribution import HipAttribution
@@ -450,7 +452,7 @@ def bench_ig(ctx, B, chunk):
     cfg = syn.large_config()
     sd = syn.embedder_weights(cfg)
     coef, icpt = syn.logreg_weights(cfg.hidden_size)
-    att = HipAttribution(HipEmbedder(cfg, sd, coef, icpt, dev, precision="f16"))
+    att = HipAttribution(HipEmbedder(cfg, sd, coef, icpt, dev, precision=precision))
     w = syn.make_clips(B, 64000).to(dev)
     att.integrated_gradients(w, n_steps=max(1, chunk // B), internal_batch_size=chunk)      # warm-up: builds the one chunk-shaped workspace
     torch.cuda.synchronize()
@@ -463,11 +465,14 @@ def bench_ig(ctx, B, chunk):
     rows = min(chunk, 50 * B) // B * B if chunk >= B else B
     fwd = att.emb.flops(rows, 64000) / rows
     out = {"workload": f"BASELINE config 5, one GPU's share: IntegratedGradients n_steps=50, wav2vec2-large, {B} clips x 4 s, internal batch {chunk}",
-           "value": round(50 * B / dt, 1), "unit": "path points/s", "clips_per_s": round(B / dt, 3), "seconds": round(dt, 3), "dtype": "f16",
+           "value": round(50 * B / dt, 1), "unit": "path points/s", "clips_per_s": round(B / dt, 3), "seconds": round(dt, 3), "dtype": precision,
            "fwd_gflop_per_point": round(fwd / 1e9, 1), "approx_tflops_fwd_plus_dgrad": round(2 * fwd * 50 * B / dt / 1e12, 1),
-           "finite": bool(torch.isfinite(attr).all().item()), "roofline": gemm_roofline(G, "f16")}
+           "finite": bool(torch.isfinite(attr).all().item()), "roofline": gemm_roofline(G, precision)}
     del att, attr, w
     torch.cuda.empty_cache()
+    if both and precision == "f32":
+        r = bench_ig(ctx, B, chunk, "f16", both=False)
+        out["f16"] = {k: r[k] for k in ("value", "unit", "seconds", "approx_tflops_fwd_plus_dgrad", "finite", "roofline")}
     return out
 
 
@@ -475,8 +480,8 @@ def ig_line(ctx, r):
     args, world = ctx["args"], ctx["world"]
     return {"metric": "IntegratedGradients path points/sec (50 steps, wav2vec2-large, 4 s clips)", "value": round(r["value"] * world, 1),
             "unit": "path points/s", "n_gpus": world, "steps": 1, "warmup": 1, "ms_per_step": round(1e3 * r["seconds"], 1), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic", "config": {"workload": r["workload"]},
-            "roofline": r["roofline"], "cpu_baseline": None}
+            "scaling": "weak", "vs_baseline": None, "dtype": r["dtype"], "data": "synthetic", "config": {"workload": r["workload"]},
+            "roofline": r["roofline"], "f16": r.get("f16"), "cpu_baseline": None}
 
 
 # ------------------------------------------------------------------------------------------ CPU baseline
