@@ -54,7 +54,7 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=BATCH)
-    ap.add_argument("--workload", choices=("explain", "hifigan", "ig", "dataset"), default="explain")
+    ap.add_argument("--workload", choices=("explain", "hifigan", "ig", "dataset", "xlsr2b"), default="explain")
     ap.add_argument("--precision", choices=("f32", "f16"), default="f32", help="headline precision of the explain workload")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (f16 / hifigan / ig keys)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -140,6 +140,12 @@ def main():
         line = hifigan_line(ctx, bench_hifigan(ctx, args.batch if args.batch != BATCH else 256, args.steps, args.warmup))
     elif args.workload == "ig":
         line = ig_line(ctx, bench_ig(ctx, 16, 64, args.precision))
+    elif args.workload == "xlsr2b":
+        r = bench_xlsr2b(ctx, args.precision, args.steps if args.steps != 10 else 3, min(args.warmup, 1) or 1)
+        line = {"metric": "explanations/sec (16 kHz, 4 s clips), XLS-R-2B-width embedder", "value": r["value"],
+                "unit": "explanations/s", "n_gpus": world, "steps": r["steps"], "warmup": 1, "ms_per_step": r["ms_per_step"], "higher_is_better": True,
+                "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic", "config": {"workload": r["workload"]},
+                "lmac": r["lmac"], "roofline": r["roofline"], "pipeline_tflops": r["pipeline_tflops"], "cpu_baseline": None}
     elif args.workload == "dataset":
         r = bench_dataset(ctx, args.precision)
         line = {"metric": "explanations/sec over a host-resident data set (PCIe upload included)", "value": r["value"], "unit": "explanations/s",
@@ -155,14 +161,14 @@ def main():
 
 
 # ------------------------------------------------------------------------------------------ the explanation step
-def run_explain(ctx, precision, steps, warmup, vocoder=False):
+def run_explain(ctx, precision, steps, warmup, vocoder=False, cfg=None):
     """Time `steps` explanation steps in one precision; returns the numbers of that run.  `vocoder`: the north-star variant
     in which both resyntheses are re-rendered by the HiFi-GAN V1 vocoder (mel front end + generator, fp16 operands) before
     the classifier re-forward."""
     import torch
     from addvisor_hip import gemm as G, pipeline as P, synthetic as syn
     args, dev, rank, world, dist = ctx["args"], ctx["dev"], ctx["rank"], ctx["world"], ctx["dist"]
-    cfg = syn.base_config()
+    cfg = cfg or syn.base_config()
     emb_sd = syn.embedder_weights(cfg)
     coef, icpt = syn.logreg_weights(cfg.hidden_size)
     unet_sd = syn.unet_weights()
@@ -212,18 +218,21 @@ def run_explain(ctx, precision, steps, warmup, vocoder=False):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     res = dict(precision=precision, elapsed=elapsed, steps=steps, value=world * B * steps / elapsed, metrics=metrics,
-               flops_step=pipe.flops(B), roofline=gemm_roofline(G, precision, args.tune), cfg=cfg, weights=(emb_sd, coef, icpt, unet_sd))
+               flops_step=pipe.flops(B), roofline=gemm_roofline(G, precision, args.tune, committed=(cfg.hidden_size == 768 and not vocoder and B == BATCH)),
+               cfg=cfg, weights=(emb_sd, coef, icpt, unet_sd))
     del pipe, batches
     torch.cuda.empty_cache()
     return res
 
 
-def gemm_roofline(G, precision, tuned=False):
+def gemm_roofline(G, precision, tuned=False, committed=False):
+    """`committed`: attach the committed PMC traffic figure (profiles/*gemm_traffic.json) -- only meaningful for the default explain
+    workload those passes ran; every other workload reports traffic null unless it measures its own."""
     ms, flops, n = G.PROFILE.summary()                                     # the tile instantiation with the largest total time
     kernel = getattr(G.PROFILE, "kernel", "gemm_f16_kernel")              # ... under the name rocprofv3 lists it
     achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else None
     peak = PEAK[precision]
-    traffic, source = committed_traffic(kernel) if not tuned else (None, None)
+    traffic, source = committed_traffic(kernel) if (committed and not tuned) else (None, None)
     return {"kernel": kernel + (" (tuned tile choice)" if tuned else ""), "bound": "mfma",
             "achieved": None if achieved is None else round(achieved, 1), "peak": round(peak, 1), "peak_note": PEAK_NOTE[precision],
             "unit": "TFLOP/s", "frac": None if achieved is None else round(achieved / peak, 4),
@@ -328,6 +337,7 @@ def explain_line(ctx):
                                    "value": round(v["value"], 2), "unit": "explanations/s", "ms_per_step": round(1e3 * v["elapsed"] / v["steps"], 3),
                                    "steps": v["steps"], "dtype": f"{args.precision} (embedder, U-Net) + f16 (vocoder)",
                                    "lmac": {k: round(x, 6) for k, x in v["metrics"].items()}}
+        line["xlsr2b"] = bench_xlsr2b(ctx, args.precision)
         line["dataset"] = bench_dataset(ctx, args.precision)
         line["hifigan"] = bench_hifigan(ctx, 256, 5, 1)
         line["ig"] = bench_ig(ctx, 16, 64)
@@ -336,6 +346,24 @@ def explain_line(ctx):
         emb_sd, coef, icpt, unet_sd = head["weights"]
         line["cpu_baseline"] = cpu_baseline(cfg, emb_sd, coef, icpt, unet_sd, args.cpu_clips, L, args.cpu_threads, args.cpu_repeats)
     return line
+
+
+# ------------------------------------------------------------------------------------------ the reference's own embedder shape
+def bench_xlsr2b(ctx, precision, steps=3, warmup=1):
+    """The explanation step with the embedder the reference itself loads (classifier_embedder.py:13-16, 25: XLS-R-2B -- hidden
+    1920, 16 heads x 120, FFN 7680, layer-norm feature extractor, pre-LN encoder -- truncated to the layers hidden_states[9]
+    needs, `nn.Linear(1920, 1)` head) instead of BASELINE config 2's wav2vec2-base: same 64 x 4 s batch, same U-Net, three
+    embedder passes per explanation.  Seeded random weights (the checkpoint is private)."""
+    from addvisor_hip import synthetic as syn
+    cfg = syn.xlsr2b_config(num_hidden_layers=10)
+    r = run_explain(ctx, precision, steps, warmup, cfg=cfg)
+    B = ctx["args"].batch
+    return {"workload": f"explanation step with the reference's embedder shape: XLS-R-2B width (hidden 1920, 16 x 120 heads, FFN 7680, 9 encoder "
+                        f"layers to hidden_states[9]) + logreg(1920) + U-Net, batch {B} x 4 s, one GPU",
+            "value": round(r["value"], 2), "unit": "explanations/s", "ms_per_step": round(1e3 * r["elapsed"] / r["steps"], 2), "steps": r["steps"],
+            "dtype": precision, "gflop_per_explanation": round(r["flops_step"] / B / 1e9, 1),
+            "pipeline_tflops": round(r["flops_step"] * r["steps"] / r["elapsed"] / 1e12, 1),
+            "lmac": {k: round(v, 6) for k, v in r["metrics"].items()}, "roofline": r["roofline"]}
 
 
 # ------------------------------------------------------------------------------------------ BASELINE config 4 (one GPU's loop)

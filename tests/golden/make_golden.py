@@ -207,6 +207,7 @@ def main():
     part_lmac_metrics()
     part_large()
     part_unet5()
+    part_xlsr2b()
 
 
 def part_lmac_metrics():
@@ -237,6 +238,26 @@ def part_large():
          layer_absmax=np.array([h.abs().max().item() for h in hs[:10]]))
 
 
+def part_xlsr2b():
+    """The reference's OWN embedder shape (classifier_embedder.py:13-16, 25: XLS-R-2B -- hidden 1920, 16 heads x 120, FFN 7680,
+    layer-norm feature extractor, pre-LN encoder -- truncated; `nn.Linear(1920, 1)` head), 10 encoder layers (layers beyond
+    hidden_states[9] need no weights), one 4 s clip through the reference's own extract_features: moments, a corner and the
+    pooled vector of hidden_states[9], the per-layer moments of hidden_states[0..9] from the HF model the reference calls,
+    and the reference TorchLogReg's logit / probability of the pooled vector."""
+    cfg = syn.xlsr2b_config(num_hidden_layers=10)
+    ce, apm, adv, lf = import_reference(cfg)
+    m = build_hf(cfg)
+    apm.wav2vec2 = m
+    w = syn.make_clips(1, 64000)
+    f = apm.AudioProcessor(audio_length=4).extract_features(w)          # [199, 1920]
+    hs = m(ce.zero_mean_unit_var_norm(w), output_hidden_states=True).hidden_states
+    logit, prob = ce.TorchLogReg()(f.mean(0, keepdim=True))
+    save("embedder_xlsr2b_4s.npz", shape=np.array(f.shape), mean=f.double().mean(), absmax=f.abs().max(), std=f.double().std(),
+         corner=f[:8, :16], pooled=f.mean(0), logit=logit, prob=prob,
+         layer_mean=np.array([h.double().mean().item() for h in hs[:10]]), layer_std=np.array([h.double().std().item() for h in hs[:10]]),
+         layer_absmax=np.array([h.abs().max().item() for h in hs[:10]]))
+
+
 def part_unet5():
     """The reference's default clip length (audio_length = 5: T = 249 frames, 512 x 248 U-Net grid, SURVEY.md §8 sizes in
     brackets), two clips: the reference UNet's mask (addvisor.py:12-84) on the reference STFT magnitude -- subsampled values,
@@ -253,7 +274,7 @@ def part_unet5():
          band=int(((full - 0.5).abs() < 1e-3).sum()), closest=float((full - 0.5).abs().min()))
 
 
-PARTS = {"lmac_metrics": part_lmac_metrics, "large": part_large, "unet5": part_unet5}
+PARTS = {"lmac_metrics": part_lmac_metrics, "large": part_large, "unet5": part_unet5, "xlsr2b": part_xlsr2b}
 
 
 if __name__ == "__main__":

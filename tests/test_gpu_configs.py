@@ -87,6 +87,62 @@ def test_large_embedder_4s(gpu_device, golden, large_model, precision):
     assert (hid[0].mean(0).cpu() - torch.from_numpy(g["pooled"])).abs().max().item() <= tol_max
 
 
+# ------------------------------------------------------------------------------------------ the reference's own embedder shape
+@pytest.fixture(scope="module")
+def xlsr2b_model():
+    cfg = syn.xlsr2b_config(num_hidden_layers=10)
+    sd = syn.embedder_weights(cfg)
+    coef, icpt = syn.logreg_weights(cfg.hidden_size)
+    return cfg, sd, coef, icpt
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16"])
+def test_xlsr2b_embedder_4s(gpu_device, golden, xlsr2b_model, precision):
+    """classifier_embedder.py:13-16, 25: XLS-R-2B at FULL width (hidden 1920, 16 heads x 120 -> the streaming head-dim-120
+    attention, FFN 7680, layer-norm feature extractor, pre-LN encoder), truncated to the layers hidden_states[9] needs, one
+    4 s clip (audioprocessor.py:69-77), against the oracle and the reference-generated fixture.  Tolerances as for the large
+    model: relative to the un-normalised residual stream's magnitude."""
+    cfg, sd, coef, icpt = xlsr2b_model
+    w = syn.make_clips(1, 64000)
+    emb = HipEmbedder(cfg, sd, coef, icpt, gpu_device, precision=precision)
+    hid, logit, prob = emb.forward(w.to(gpu_device))
+    ref_h = wav2vec2_ref.hidden_states(wav2vec2_ref.zero_mean_unit_var_norm(w), sd, cfg, upto=9)[9]
+    ref_logit, _ = wav2vec2_ref.logreg(ref_h.mean(1), coef, icpt)
+    amax = ref_h.abs().max().item()
+    err = (hid.cpu() - ref_h).abs()
+    le = (logit.cpu() - ref_logit).abs().max().item()
+    print(f"XLS-R-2B shape {precision}: hidden max err {err.max():.3e} mean {err.mean():.3e}, |ref|max {amax:.2f}, logit err {le:.3e}")
+    tol_max, tol_mean, tol_logit = (2e-5 * amax + 1e-5, 2e-6 * amax + 1e-6, 1e-4) if precision == "f32" else (4e-3 * amax, 4e-4 * amax, 1e-2)
+    assert err.max().item() <= tol_max and err.mean().item() <= tol_mean and le <= tol_logit
+    g = golden("embedder_xlsr2b_4s.npz")                                   # the reference's own extract_features + TorchLogReg
+    assert tuple(hid.shape[1:]) == tuple(g["shape"]) == (199, 1920)
+    assert (hid[0, :8, :16].cpu() - torch.from_numpy(g["corner"])).abs().max().item() <= tol_max
+    assert (hid[0].mean(0).cpu() - torch.from_numpy(g["pooled"])).abs().max().item() <= tol_max
+    assert abs(logit.item() - float(g["logit"].reshape(-1)[0])) <= tol_logit
+    assert abs(prob.item() - float(g["prob"].reshape(-1)[0])) <= tol_logit
+    # batch invariance at this width (utterances shard): clip 0 of a 3-clip batch is bit-identical to the single clip
+    w3 = torch.cat([w, syn.make_clips(2, 64000, seed=5)], 0)
+    hid3, _, _ = emb.forward(w3.to(gpu_device))
+    assert torch.equal(hid3[0], hid[0])
+
+
+def test_xlsr2b_input_gradient_1s(gpu_device, xlsr2b_model):
+    """The fp32-class gradient chain at the reference's width (head dim 120: the one-matrix-in-LDS form of the fp32-MFMA
+    attention backward, K = 7680 dgrad GEMMs), 1 s clip, against fp32 autograd through the oracle."""
+    from addvisor_hip.embedder_grad import EmbedderGrad
+    cfg, sd, coef, icpt = xlsr2b_model
+    w = syn.make_clips(1, 16000, seed=3)
+    eg = EmbedderGrad(HipEmbedder(cfg, sd, coef, icpt, gpu_device, precision="f32"))
+    eg.forward(w.to(gpu_device))
+    dx = eg.backward().cpu()
+    with torch.enable_grad():
+        ref = attribution_ref.input_gradient(w, sd, cfg, coef, icpt)
+    rel = ((dx - ref).abs().max() / ref.abs().max()).item()
+    cos = torch.nn.functional.cosine_similarity(dx.double().flatten(), ref.double().flatten(), dim=0).item()
+    print(f"XLS-R-2B shape input gradient [f32]: max rel err {rel:.3e}, cosine {cos:.8f}")
+    assert rel < 1e-4 and cos > 0.999999
+
+
 @pytest.mark.parametrize("precision", ["f32", "f16"])
 def test_ig_50_steps_large(gpu_device, large_model, precision):
     """captum_saliency.py:131-135 at config 5's model and step count: IntegratedGradients(n_steps=50, gausslegendre, zero

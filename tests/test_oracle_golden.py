@@ -106,6 +106,29 @@ def test_embedder_large_full(golden):
         assert abs(hs[i].double().std().item() - g["layer_std"][i]) < 1e-4 * g["layer_std"][i], i
 
 
+def test_embedder_xlsr2b_full(golden):
+    """The reference's OWN embedder shape (classifier_embedder.py:13-16, 25: XLS-R-2B, hidden 1920, 16 heads x 120, FFN 7680),
+    10 encoder layers, one 4 s clip: the oracle against the reference's extract_features / TorchLogReg and the HF model's
+    per-layer moments (tests/golden/make_golden.py xlsr2b)."""
+    g = golden("embedder_xlsr2b_4s.npz")
+    cfg = syn.xlsr2b_config(num_hidden_layers=10)
+    sd = syn.embedder_weights(cfg)
+    w = syn.make_clips(1, 64000)
+    hs = wav2vec2_ref.hidden_states(wav2vec2_ref.zero_mean_unit_var_norm(w), sd, cfg, upto=9)
+    f = hs[9][0]
+    assert tuple(f.shape) == tuple(g["shape"]) == (199, 1920)
+    amax = float(g["absmax"])
+    close(f[:8, :16], g["corner"], 2e-5 * amax + 1e-5)
+    close(f.mean(0), g["pooled"], 1e-5 * amax + 1e-5)
+    coef, icpt = syn.logreg_weights(cfg.hidden_size)
+    logit, prob = wav2vec2_ref.logreg(f.mean(0, keepdim=True), coef, icpt)
+    close(logit, g["logit"], 1e-4)
+    close(prob, g["prob"], 1e-5)
+    for i in range(10):
+        assert abs(hs[i].double().mean().item() - g["layer_mean"][i]) < 1e-5 + 1e-4 * abs(g["layer_mean"][i]), i
+        assert abs(hs[i].double().std().item() - g["layer_std"][i]) < 1e-4 * g["layer_std"][i], i
+
+
 def test_unet(golden):
     g = golden("unet.npz")
     sd = syn.unet_weights()
