@@ -16,11 +16,12 @@ fused line-tile kernels keep their intermediate in LDS with zero padding, so tha
 """
 from __future__ import annotations
 
-from typing import Dict, Tuple
+from typing import Dict, Optional, Tuple
 
 import torch
 
 from . import _lib, gemm as G
+from .embedder import default_precision
 from .synthetic import HifiganConfig
 
 HALO = 32          # >= the largest "same" padding: (11 - 1) * 5 / 2 = 25
@@ -28,13 +29,16 @@ HALO = 32          # >= the largest "same" padding: (11 - 1) * 5 / 2 = 25
 
 class HipHifigan:
     def __init__(self, cfg: HifiganConfig, sd: Dict[str, torch.Tensor], device, line_tile: bool = True, fuse: bool = True,
-                 padding_mode: str = "zeros", inference_padding: int = 0, precision: str = "f16"):
+                 padding_mode: str = "zeros", inference_padding: int = 0, precision: Optional[str] = None):
         """``line_tile``: run the 32- / 64-channel ResBlock convolutions on the weights-in-LDS kernel
         (``advh_conv_taps_f16``) instead of the implicit GEMM; ``fuse``: whole ResBlock steps in one kernel where both
         weight tensors fit in LDS (``advh_resblock_pair_f16``).  ``padding_mode`` / ``inference_padding``: see the module
-        docstring.  ``precision``: "f16" (default: the vocoder's stated tolerance is on waveforms) or "f32" -- the
-        fp32-class mode of the explanation path (split-format maps, three MFMAs per product; implicit GEMM only)."""
+        docstring.  ``precision``: None = ``ADDVISOR_PRECISION`` (default "f32": the fp32-class mode of the explanation path
+        -- split-format maps, three MFMAs per product; the reference runs the vocoder in fp32, hifigan.py:180) or "f16"
+        (fp16 operands, LDS line-tile kernels; stated tolerance 2e-2 on waveforms)."""
         _lib.init()
+        precision = precision or default_precision()
+        self._ctor = dict(line_tile=line_tile, fuse=fuse, padding_mode=padding_mode, inference_padding=inference_padding)
         if precision not in ("f16", "f32"):
             raise ValueError("precision must be 'f16' or 'f32'")
         self.precision, self.split = precision, precision == "f32"
@@ -59,6 +63,13 @@ class HipHifigan:
         self.post_w = self.sd["conv_post.weight"][0].t().contiguous().to(device)       # [k][C]
         self.post_b = float(self.sd["conv_post.bias"][0])
         self._ws: Dict[Tuple[int, int], dict] = {}
+
+    def with_precision(self, precision: str) -> "HipHifigan":
+        """This generator at ``precision`` (itself if it already is): ``ExplainPipeline`` runs its vocoder at the path's
+        precision, so that the explanation has ONE arithmetic class."""
+        if precision == self.precision:
+            return self
+        return type(self)(self.cfg, self.sd, self.dev, precision=precision, **self._ctor)
 
     def _workspace(self, B: int, T: int) -> dict:
         key = (B, T)

@@ -32,10 +32,12 @@ class ExplainPipeline:
         re-rendered by the vocoder (mel front end of hifigan.py:163-178 -> HiFi-GAN V1 -> crop to the clip length)
         before the classifier re-forward -- the "masked spectrogram -> vocoder -> classifier" variant of the path."""
         self.dev = device
-        self.vocoder = vocoder
         self.L = int(audio_length * sampling_rate)
         self.hop, self.win, self.domain = hop, win, domain
         self.precision = precision or default_precision()
+        # the vocoder runs at the path's precision: one arithmetic class per explanation (a generator built at another
+        # precision is rebuilt from its own weights)
+        self.vocoder = None if vocoder is None else vocoder.with_precision(self.precision)
         self.embedder = HipEmbedder(emb_cfg, emb_sd, coef, intercept, device, precision=self.precision)
         self.unet = HipUNet(unet_sd, device, precision=self.precision)
         # the 3B embedder batch can be split over several HIP streams: kernels of independent sub-batches then
