@@ -23,7 +23,8 @@ steps.  `cpu_baseline` times the CPU oracle (plain torch, the reference arithmet
 workload on this host's cores (rank 0, N = 1 only).  The default N = 1 invocation also measures BASELINE config 3
 (`"hifigan"`: HiFi-GAN V1, 256 x 251 mel frames), config 5's per-GPU share (`"ig"`: IntegratedGradients, 50 steps x
 16 clips, wav2vec2-large, fp32-class gradient chain; the fp16 chain under its `"f16"` sub-key), the vocoder variant of the step (`"explain_vocoder"`) and one rank's data-set loop of config 4
-with the PCIe upload inside the timed region (`"dataset"`: 4 133 clips from pinned host memory, ragged last batch) and
+through the drop-in `LMAC_metrics.run_addvisor_metrics` itself (`"dataset"`: 8 905 clips from an in-memory Dataset in pinned host memory,
+DataLoader + per-item upload + collate inside the timed region, ragged last batch) and
 appends them as extra keys; `--workload hifigan|ig|dataset` runs one of them as the headline.
 """
 import argparse
@@ -149,7 +150,7 @@ def main():
     elif args.workload == "dataset":
         r = bench_dataset(ctx, args.precision)
         line = {"metric": "explanations/sec over a host-resident data set (PCIe upload included)", "value": r["value"], "unit": "explanations/s",
-                "n_gpus": 1, "steps": 1, "warmup": 1, "ms_per_step": round(1e3 * r["seconds"], 1), "higher_is_better": True, "scaling": "weak",
+                "n_gpus": world, "steps": 1, "warmup": 1, "ms_per_step": round(1e3 * r["seconds"], 1), "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": args.precision, "data": "synthetic", "config": {"workload": r["workload"]}, "lmac": r["lmac"],
                 "cpu_baseline": None}
     else:
@@ -368,56 +369,86 @@ def bench_xlsr2b(ctx, precision, steps=3, warmup=1):
 
 # ------------------------------------------------------------------------------------------ BASELINE config 4 (one GPU's loop)
 def bench_dataset(ctx, precision, n_clips=DATASET_SHARE, pool=512):
-    """The dataset loop of LMAC_metrics.run_addvisor_metrics (LMAC_metrics.py:117-172) as one rank of config 4 runs it:
-    clips live in HOST memory (pinned), every batch of 64 is uploaded over PCIe on a copy stream while the previous batch
-    computes (two device buffers), the last batch is ragged (n_clips % 64 != 0), the per-clip probabilities are gathered and
-    the five metrics reduced at the end.  The rate INCLUDES the upload -- unlike the headline, whose batches are resident."""
+    """BASELINE config 4 as one rank runs it, through the reference driver's OWN entry point: the drop-in
+    `LMAC_metrics.run_addvisor_metrics` (LMAC_metrics.py:117-172) over an in-memory `Dataset` of `n_clips` 4 s clips per
+    rank -- `DataLoader(batch_size=64, collate_fn=LMAC_metrics.collate_fn)`, every item uploaded from pinned HOST memory
+    inside `__getitem__` (`.to(device)`, LMAC_metrics.py:106), ragged last batch, the fused explanation step per batch, one
+    gather of the per-clip probabilities and the five metrics at the end.  The rate INCLUDES the loader, the per-item PCIe
+    uploads and the collate -- unlike the headline, whose batches are resident.  Under `--gpus N` the function shards the
+    `N * n_clips` clips itself (block partition -> RCCL all_gather), every rank times its own walk and the line reports
+    total clips / max-over-ranks time."""
+    import contextlib
     import torch
-    from addvisor_hip import pipeline as P, synthetic as syn
-    args, dev, rank, world = ctx["args"], ctx["dev"], ctx["rank"], ctx["world"]
-    cfg = syn.base_config()
-    coef, icpt = syn.logreg_weights(cfg.hidden_size)
-    pipe = P.ExplainPipeline(cfg, syn.embedder_weights(cfg), coef, icpt, syn.unet_weights(), dev, audio_length=AUDIO_LENGTH, precision=precision)
+    from addvisor_hip import runtime as rt, synthetic as syn
+    args, dev, rank, world, dist = ctx["args"], ctx["dev"], ctx["rank"], ctx["world"], ctx["dist"]
+    saved = {k: os.environ.get(k) for k in ("ADDVISOR_PRECISION", "ADDVISOR_EMBEDDER")}
+    os.environ["ADDVISOR_PRECISION"], os.environ["ADDVISOR_EMBEDDER"] = precision, "base"
+    rt.reset()
+    import LMAC_metrics
+    LMAC_metrics._model = None
+    LMAC_metrics._pipes.clear()
+    old_len = LMAC_metrics.audio_processor.audio_length
+    LMAC_metrics.audio_processor.audio_length = AUDIO_LENGTH
     B, L = BATCH, AUDIO_LENGTH * 16000
-    host = syn.make_clips(pool, L, first=rank * pool).pin_memory()            # the "files": cycled through to reach n_clips
-    idx = P.shard_indices(n_clips * world, rank, world)                        # this rank's contiguous block of the data set
-    starts = list(range(idx.start, idx.stop, B))
-    bufs = [torch.empty(B, L, device=dev), torch.empty(B, L, device=dev)]
-    copy_s, cur = torch.cuda.Stream(device=dev), torch.cuda.current_stream()
-    ready = [torch.cuda.Event(), torch.cuda.Event()]
-    freed = [torch.cuda.Event(), torch.cuda.Event()]
+    host = syn.make_clips(pool, L).pin_memory()                                  # the "files": cycled through to reach the data-set size
+    n_total = n_clips * world
 
-    def run():
-        probs = []
-        for j, s0 in enumerate(starts):
-            n = min(B, idx.stop - s0)
-            k = j & 1
-            off = (s0 * 7) % (pool - B)
+    copy_s = torch.cuda.Stream(device=dev)
+
+    class InMemory(torch.utils.data.Dataset):
+        def __len__(self):
+            return n_total
+
+        def __getitem__(self, i):
+            # LMAC_metrics.py:101-106: per-item upload.  The copy is issued on a copy stream, so the items of batch k+1 (the loader
+            # runs ahead of the GPU: nothing in the loop synchronises) cross PCIe while batch k computes; the compute stream
+            # waits for the copy stream, never the other way round.
+            cur = torch.cuda.current_stream()
             with torch.cuda.stream(copy_s):
-                if j >= 2:
-                    copy_s.wait_event(freed[k])                                # the batch that used this buffer has been consumed
-                bufs[k][:n].copy_(host[off:off + n], non_blocking=True)
-                ready[k].record(copy_s)
-            cur.wait_event(ready[k])
-            out = pipe.explain(bufs[k][:n])
-            freed[k].record(cur)
-            probs.append(torch.cat([out["predictions"], out["theta_out"], out["masked_predictions"]], 1))
-        allp = torch.cat(probs, 0)
-        return P.lmac_metrics(allp[:, 0].contiguous(), allp[:, 1].contiguous(), allp[:, 2].contiguous())
+                t = host[(i * 7) % pool].to(dev, non_blocking=True)
+            cur.wait_stream(copy_s)
+            t.record_stream(cur)
+            return t, f"clip{i}.wav"
 
-    pipe.explain(bufs[0]); pipe.explain(bufs[0][:(idx.stop - idx.start) % B or B])     # build both workspaces (full and ragged batch) outside the timed region
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    metrics = run()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    n_local = idx.stop - idx.start
-    out = {"workload": f"BASELINE config 4 as one rank runs it: {n_local} clips x 4 s (one of eight ranks' share of an ASVspoof2019-LA-sized set of {DATASET_CLIPS}) "
-                       f"from pinned host memory in batches of {B} (last batch {n_local % B or B}), "
-                       "upload overlapped on a copy stream, LMAC metrics at the end; wav2vec2-base + U-Net",
-           "value": round(n_local / dt, 1), "unit": "explanations/s (PCIe upload included)", "seconds": round(dt, 3), "clips": n_local, "dtype": precision,
-           "upload_GB": round(n_local * L * 4 / 1e9, 3), "lmac": {k: round(v, 6) for k, v in metrics.items()}}
-    del pipe, bufs, host
+    class Head(torch.utils.data.Dataset):                                            # warm-up: one full and one ragged batch build both workspaces
+        def __len__(self):
+            return B + (n_clips % B or B)
+
+        def __getitem__(self, i):
+            return host[i % pool].to(dev), f"w{i}.wav"
+
+    try:
+        with contextlib.redirect_stdout(sys.stderr):                                 # the driver prints its five lines; stdout carries the JSON line only
+            if dist is None:
+                LMAC_metrics.run_addvisor_metrics("", "", batch_size=B, dataset=Head())
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+            t0 = time.perf_counter()
+            metrics = LMAC_metrics.run_addvisor_metrics("", "", batch_size=B, dataset=InMemory())
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.rehearse else dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+    finally:
+        LMAC_metrics.audio_processor.audio_length = old_len
+        LMAC_metrics._model = None
+        LMAC_metrics._pipes.clear()
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        rt.reset()
+    out = {"workload": f"BASELINE config 4 through LMAC_metrics.run_addvisor_metrics (the reference driver's entry point): {n_clips} clips x 4 s per rank "
+                       f"(one of eight ranks' share of an ASVspoof2019-LA-sized set of {DATASET_CLIPS}) from an in-memory Dataset in pinned host memory, "
+                       f"DataLoader batches of {B} (last batch {n_clips % B or B}), per-item upload in __getitem__, fused explanation step, LMAC metrics "
+                       "at the end; wav2vec2-base + U-Net",
+           "value": round(n_total / dt, 1), "unit": "explanations/s (loader + PCIe upload included)", "seconds": round(dt, 3), "clips": n_total,
+           "n_gpus": world, "dtype": precision, "upload_GB": round(n_total * L * 4 / 1e9, 3), "lmac": {k: round(v, 6) for k, v in metrics.items()}}
+    del host
     torch.cuda.empty_cache()
     return out
 

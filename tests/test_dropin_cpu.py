@@ -250,3 +250,46 @@ def test_bench_self_launch_starts_ranks_and_propagates_failure():
     env = dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=120, env=env)
     assert r.returncode != 0 and "--gpus 2 but WORLD_SIZE=3" in (r.stdout + r.stderr)
+
+
+def test_collate_is_lazy_and_lazy_tensors_behave(monkeypatch):
+    """SURVEY.md D12 / LMAC_metrics.py:109-114: ``collate_fn`` returns the reference's 5-tuple but does no device work of its
+    own -- magnitude / phase / features are computed on first use only (the fused ``run_addvisor_metrics`` never uses them)."""
+    import LMAC_metrics
+    calls = {"stft": 0, "feat": 0}
+
+    def fake_stft(w):
+        calls["stft"] += 1
+        return w * (1 + 0j), w.abs(), torch.zeros_like(w)
+
+    def fake_feat(w):
+        calls["feat"] += 1
+        return w[:, None, :4].repeat(1, 3, 1)
+
+    monkeypatch.setattr(LMAC_metrics.audio_processor, "compute_stft", fake_stft)
+    monkeypatch.setattr(LMAC_metrics.audio_processor, "extract_features", fake_feat)
+    clips = [(torch.full((8,), float(i) - 1.0), f"c{i}.wav") for i in range(3)]
+    waves, mag, ph, feats, names = LMAC_metrics.collate_fn(clips)
+    assert waves.shape == (3, 8) and names == ("c0.wav", "c1.wav", "c2.wav")
+    assert calls == {"stft": 0, "feat": 0} and not mag.materialized and not feats.materialized
+    assert isinstance(mag, LMAC_metrics.LazyTensor) and "pending" in repr(mag)
+    # first use computes; magnitude and phase share ONE STFT; tensor protocol: attributes, indexing, arithmetic, torch.* calls
+    assert mag.shape == (3, 8) and calls["stft"] == 1
+    assert torch.equal(ph[0], torch.zeros(8)) and calls["stft"] == 1
+    assert torch.equal(mag + 1, waves.abs() + 1) and torch.equal(2 * mag, 2 * waves.abs()) and torch.equal(torch.log1p(mag), torch.log1p(waves.abs()))
+    assert torch.equal(feats.mean(dim=1), waves[:, :4]) and calls["feat"] == 1 and len(feats) == 3
+    assert feats.materialized and mag.materialized
+
+
+def test_loss_scaler_backs_off_and_regrows():
+    from addvisor_hip.lmac_loss import LossScaler
+    s = LossScaler(4096.0, growth_interval=3)
+    assert s.backoff() and s.scale == 256.0                      # kept for the following steps
+    for _ in range(3):
+        s.good()
+    assert s.scale == 512.0                                      # grows back by powers of two ...
+    for _ in range(30):
+        s.good()
+    assert s.scale == 4096.0                                     # ... up to the initial value, never beyond
+    tiny = LossScaler(2.0 ** -18)
+    assert not tiny.backoff() and tiny.scale == 2.0 ** -18       # floor: the caller raises

@@ -104,28 +104,118 @@ class AudioDataset(torch.utils.data.Dataset):
         return waveform.to(self.device), os.path.basename(path)
 
 
+class LazyTensor:
+    """A tensor that is computed on first use.  ``collate_fn`` (LMAC_metrics.py:109-114) returns the STFT magnitude / phase
+    and the wav2vec2 features of every batch; the reference's loop reads none of the values it does not need, and the fused
+    HIP path recomputes nothing from them -- so they are produced only if somebody actually touches them (attribute access,
+    indexing, arithmetic, any ``torch.*`` call).  SURVEY.md D12: collate does no device work of its own."""
+    __slots__ = ("_fn", "_v")
+
+    def __init__(self, fn):
+        self._fn, self._v = fn, None
+
+    @property
+    def materialized(self) -> bool:
+        return self._v is not None
+
+    def materialize(self) -> torch.Tensor:
+        if self._v is None:
+            self._v, self._fn = self._fn(), None
+        return self._v
+
+    def __getattr__(self, name):
+        return getattr(self.materialize(), name)
+
+    def __getitem__(self, i):
+        return self.materialize()[i]
+
+    def __len__(self):
+        return len(self.materialize())
+
+    def __iter__(self):
+        return iter(self.materialize())
+
+    def __repr__(self):
+        return f"LazyTensor({'pending' if self._v is None else repr(self._v)})"
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        un = lambda a: a.materialize() if isinstance(a, LazyTensor) else a
+        return func(*[un(a) for a in args], **{k: un(v) for k, v in (kwargs or {}).items()})
+
+
+def _binop(name):
+    def op(self, *a):
+        return getattr(self.materialize(), name)(*[x.materialize() if isinstance(x, LazyTensor) else x for x in a])
+    op.__name__ = name
+    return op
+
+
+for _n in ("add", "radd", "sub", "rsub", "mul", "rmul", "truediv", "rtruediv", "pow", "matmul", "neg", "abs", "lt", "le", "gt", "ge", "eq", "ne"):
+    setattr(LazyTensor, f"__{_n}__", _binop(f"__{_n}__"))
+
+
+def _tensor(x):
+    return x.materialize() if isinstance(x, LazyTensor) else x
+
+
 def collate_fn(batch):
-    """LMAC_metrics.py:109-114: same return tuple; the STFT and the embedder run on the GPU stream."""
+    """LMAC_metrics.py:109-114: same return tuple ``(waveforms, magnitude, phase, features, filenames)``.  The reference runs
+    the STFT and a full embedder pass here, on the loader's thread; this collate only stacks the clips -- magnitude, phase
+    and features are ``LazyTensor``s, computed on first use (``run_addvisor_metrics`` below never needs them: the fused step
+    works from the waveforms)."""
     waveforms, filenames = zip(*batch)
     waveforms = torch.stack(waveforms, dim=0)
-    _, magnitude, phase = audio_processor.compute_stft(waveforms)
-    features = audio_processor.extract_features(waveforms)
+    stft = LazyTensor(lambda: audio_processor.compute_stft(waveforms))          # one STFT serves magnitude and phase
+    magnitude = LazyTensor(lambda: stft.materialize()[1])
+    phase = LazyTensor(lambda: stft.materialize()[2])
+    features = LazyTensor(lambda: audio_processor.extract_features(waveforms))
     return waveforms, magnitude, phase, features, filenames
 
 
-def explain_batch(waveforms, magnitude, phase, domain="log1p"):
+_pipes = {}
+
+
+def _pipeline(domain="log1p"):
+    """The fused explanation step (addvisor_hip.pipeline.ExplainPipeline) over the process-wide embedder and this module's
+    U-Net: STFT -> (X, |X|) -> mask -> complex masked ISTFT x2 (no phase, no atan2 / sincos) -> ONE 3B-clip embedder pass."""
+    ap = audio_processor
+    unet = get_model()._engine(device)
+    emb = _rt.hip_embedder()
+    key = (float(ap.audio_length), ap.sampling_rate, ap.hop_length, ap.win_length, domain, id(unet), id(emb))
+    if key not in _pipes:
+        _pipes.clear()                                                            # a reloaded checkpoint / new geometry replaces the old plan
+        _pipes[key] = _P.ExplainPipeline(None, None, None, None, None, device, audio_length=ap.audio_length, sampling_rate=ap.sampling_rate,
+                                         domain=domain, hop=ap.hop_length, win=ap.win_length, embedder=emb, unet=unet)
+    return _pipes[key]
+
+
+def explain_batch(waveforms, magnitude=None, phase=None, domain="log1p"):
     """Loop body of run_addvisor_metrics (LMAC_metrics.py:125-157) for one batch; returns the three
-    probability vectors ``(predictions, theta_out, masked_predictions)``, each ``[B,1]``."""
+    probability vectors ``(predictions, theta_out, masked_predictions)``, each ``[B,1]``.
+
+    With the collate's lazy ``magnitude`` / ``phase`` (or None) the batch takes the fused step: 3 embedder passes per clip in
+    one 3B batch, the masked resynthesis straight from the complex spectrogram.  Explicit spectrogram TENSORS (a caller that
+    edited them) are honoured: mask and resynthesis are computed from exactly those."""
     ap = audio_processor
     L = int(ap.audio_length * ap.sampling_rate)
+    w = waveforms.to(device, torch.float32)
+    explicit = lambda t: t is not None and not (isinstance(t, LazyTensor) and not t.materialized)
+    if not explicit(magnitude) and not explicit(phase):
+        out = _pipeline(domain).explain(w)
+        return out["predictions"], out["theta_out"], out["masked_predictions"]
+    magnitude, phase = _tensor(magnitude), _tensor(phase)
     emb = _rt.hip_embedder()
-    _, _, probs_clean = emb.forward(waveforms.to(device, torch.float32), L, want_hidden=False)
     T = magnitude.shape[-1]
     mask = get_model()(magnitude[:, None, :512, :(T // 4) * 4])[:, 0]
     w_in, w_out = _ops.istft_masked(magnitude, phase, mask, L, domain=domain, hop=ap.hop_length, win=ap.win_length)
-    _, _, probs_in = emb.forward(w_in, L, want_hidden=False)
-    _, _, probs_out = emb.forward(w_out, L, want_hidden=False)
-    return probs_clean, probs_in, probs_out
+    B = w.shape[0]
+    allw = torch.zeros((3 * B, L), dtype=torch.float32, device=device)
+    n = min(L, w.shape[1])
+    allw[:B, :n] = w[:, :n]
+    allw[B:2 * B], allw[2 * B:] = w_in, w_out
+    _, _, p3 = emb.forward(allw, L, want_hidden=False)                            # clean, mask-in, mask-out: one 3B batch
+    return p3[:B], p3[B:2 * B], p3[2 * B:]
 
 
 def run_addvisor_metrics(dir_path1, dir_path2, batch_size=4, dataset=None):

@@ -26,20 +26,25 @@ METRIC_NAMES = ("faithfulness", "fidelity", "AD", "AI", "AG")
 class ExplainPipeline:
     def __init__(self, emb_cfg: EmbedderConfig, emb_sd, coef, intercept, unet_sd, device,
                  audio_length: float = 4, sampling_rate: int = 16000, domain: str = "log1p",
-                 hop: int = 322, win: int = 644, streams: int = 1, vocoder=None, precision: Optional[str] = None):
+                 hop: int = 322, win: int = 644, streams: int = 1, vocoder=None, precision: Optional[str] = None,
+                 embedder: Optional[HipEmbedder] = None, unet: Optional[HipUNet] = None):
         """``precision``: "f32" (fp32-class split-format kernels: the reference's arithmetic class, the default) or "f16"
         (fp16 operands; 2-3x faster); ``None`` = ``ADDVISOR_PRECISION``.  ``vocoder``: an ``addvisor_hip.hifigan.HipHifigan``; when given, the mask-in / mask-out resyntheses are
         re-rendered by the vocoder (mel front end of hifigan.py:163-178 -> HiFi-GAN V1 -> crop to the clip length)
-        before the classifier re-forward -- the "masked spectrogram -> vocoder -> classifier" variant of the path."""
+        before the classifier re-forward -- the "masked spectrogram -> vocoder -> classifier" variant of the path.
+        ``embedder`` / ``unet``: already-built engines to share (the drop-in modules' process-wide singletons) instead of
+        packing the weights again; the weight arguments are then ignored."""
         self.dev = device
         self.L = int(audio_length * sampling_rate)
         self.hop, self.win, self.domain = hop, win, domain
-        self.precision = precision or default_precision()
+        self.precision = precision or (embedder.precision if embedder is not None else default_precision())
         # the vocoder runs at the path's precision: one arithmetic class per explanation (a generator built at another
         # precision is rebuilt from its own weights)
         self.vocoder = None if vocoder is None else vocoder.with_precision(self.precision)
-        self.embedder = HipEmbedder(emb_cfg, emb_sd, coef, intercept, device, precision=self.precision)
-        self.unet = HipUNet(unet_sd, device, precision=self.precision)
+        self.embedder = embedder if embedder is not None else HipEmbedder(emb_cfg, emb_sd, coef, intercept, device, precision=self.precision)
+        self.unet = unet if unet is not None else HipUNet(unet_sd, device, precision=self.precision)
+        if self.embedder.precision != self.precision or self.unet.precision != self.precision:
+            raise ValueError("embedder, U-Net and pipeline must share one precision")
         # the 3B embedder batch can be split over several HIP streams: kernels of independent sub-batches then
         # fill each other's tail waves and launch gaps (utterances are independent)
         self.nstreams = max(1, streams)
