@@ -362,6 +362,13 @@ int advh_time_mask(const float* attr, float* mask, float* wave_in, float* wave_o
  * MFMAs with fp32 accumulation (advh_gemm_desc.split).  The entry points below are the split-format variants of the row /
  * direct kernels above: same arithmetic, `*_lo` = distance in ELEMENTS from a tensor's hi plane to its lo plane (both planes
  * share one addressing).  fp32 tensors (residual stream, masks, waveforms, statistics) are unchanged.                     */
+/* RANGE of the split format: hi is an fp16, so a value must satisfy |x| <= 65504 (the reference's fp32: 3.4e38).  Every kernel
+ * that WRITES a split tensor saturates a larger value (hi = +-65504, lo = the clamped remainder) instead of producing inf /
+ * NaN planes, and raises a sticky process-wide flag in host-mapped memory.  advh_split_overflow returns the flag (1 = some
+ * kernel that has already run met an out-of-range or NaN value since the last reset) and clears it when reset != 0; it reads
+ * host memory only -- no synchronisation -- so a kernel still in flight is seen by a later call.  Weights are range-checked
+ * on the host when they are packed.                                                                                     */
+int advh_split_overflow(int reset);
 int advh_w2v2_frontend_split(const float* wave, int64_t wave_stride, int n_in, int B, int L, const float* w0,
                              const float* bias0, const float* gamma, const float* beta, int mode, int normalize, float* stats_ws,
                              float* norm_ws, float* mr_ws, void* out, int64_t out_lo, int T0, int P0, int C0, advh_stream_t stream);

@@ -260,3 +260,44 @@ def test_run_addvisor_metrics_sharded_two_ranks(gpu_device, capsys):
         os.environ.pop("ADDVISOR_EMBEDDER", None)
         runtime.reset()
     assert single == res[0], (single, res[0])
+
+
+# ------------------------------------------------------------------------------------------ the RCCL branch, once
+def _rccl_world1_worker(port, q):
+    """One rank, backend "nccl" (= RCCL on ROCm), on the one GPU of the box: the exchange step of the path -- the fixed-order
+    all_gather of per-clip probabilities and the metric reduction on CUDA tensors -- through the same code `bench.py --gpus N`
+    and the sharded `run_addvisor_metrics` execute on a node.  Not a scaling measurement."""
+    import torch.distributed as dist
+    from addvisor_hip import pipeline as P
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        dev = torch.device("cuda:0")
+        g = torch.Generator().manual_seed(5)
+        local = torch.rand(37, 3, generator=g).to(dev)
+        allp = P.gather_probabilities(local, 37)                          # dist.all_gather on CUDA tensors over RCCL
+        t = torch.tensor([1.25], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)                          # bench.py's max-over-ranks timing reduction
+        dist.barrier()
+        m = P.lmac_metrics(allp[:, 0].contiguous(), allp[:, 1].contiguous(), allp[:, 2].contiguous())
+        q.put((dist.get_backend(), bool(torch.equal(allp, local)), float(t.item()), m))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_backend_runs_the_exchange_step_world1(gpu_device):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_world1_worker, args=(36500 + (os.getpid() % 2000), q))
+    p.start()
+    backend, same, tmax, m = q.get(timeout=300)
+    p.join(120)
+    assert p.exitcode == 0 and backend == "nccl" and same and tmax == 1.25
+    g = torch.Generator().manual_seed(5)
+    local = torch.rand(37, 3, generator=g)
+    ref = lmac_ref.lmac_summary(local[:, 0:1], local[:, 1:2], local[:, 2:3])
+    for k in ref:
+        assert abs(m[k] - ref[k]) <= 1e-5 * max(1.0, abs(ref[k])), (k, m[k], ref[k])

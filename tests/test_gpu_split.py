@@ -232,3 +232,76 @@ def test_split_xlsr_shaped_embedder(gpu_device):
     cfg = syn.tiny_config(True, hidden_size=240, num_attention_heads=2, intermediate_size=480,
                           num_conv_pos_embedding_groups=2, num_hidden_layers=10)
     _embedder_case(cfg, syn.make_clips(2, 48000, seed=33), gpu_device)
+
+
+# ------------------------------------------------------------------------------------------ the format's range contract
+def test_split_range_saturates_and_raises(gpu_device):
+    """include/addvisor_hip.h (advh_split_overflow): the split format covers |x| <= 65504 (its hi plane is an fp16; the reference's
+    fp32 reaches 3.4e38, addvisor.py:12-25 has no such limit).  An activation of 1e5 between two matrix products must not turn
+    into inf / NaN planes silently: the producing kernel saturates and raises the sticky flag, which the binding reports as
+    SplitRangeError at its next call."""
+    _lib.init()
+    _lib.lib().advh_split_overflow(1)                                     # clear whatever an earlier test left
+    M, K, N = 256, 64, 64
+    a = torch.full((M, K), 25.0)
+    w = torch.full((N, K), 62.5)                                          # y = 64 * 25 * 62.5 = 1e5 > 65504
+    w[1] = 0.5                                                            # one in-range output column: 800
+    p = G.plan_linear(M, w, None, device=gpu_device, split=True)
+    out_h = torch.zeros(2, M, N, dtype=torch.float16, device=gpu_device)
+    out_f = torch.zeros(M, N, dtype=torch.float32, device=gpu_device)
+    A = G.split_planes(a).to(gpu_device)
+    p.run(A, out_h=out_h, out_f=out_f)
+    torch.cuda.synchronize()
+    with pytest.raises(_lib.SplitRangeError):
+        _lib.check_overflow("test")
+    assert _lib.lib().advh_split_overflow(0) == 0                         # raising cleared the flag
+    y = G.join_planes(out_h.cpu())
+    assert torch.isfinite(out_h.float()).all() and torch.isfinite(y).all()   # saturated planes, not inf / NaN
+    assert (y[:, 0] - 65535.984).abs().max() < 0.02 and (y[:, 1] - 800.0).abs().max() < 1e-3
+    assert (out_f.cpu()[:, 0] - 1e5).abs().max() < 1e-2                   # the fp32 output of the same launch is not limited
+    # the error also surfaces through the ordinary call path: the next C-ABI call after the kernel ran reports it
+    p.run(A, out_h=out_h)
+    torch.cuda.synchronize()
+    with pytest.raises(_lib.SplitRangeError):
+        p.run(G.split_planes(torch.zeros(M, K)).to(gpu_device), out_h=out_h)
+    torch.cuda.synchronize()
+    _lib.lib().advh_split_overflow(1)
+    # NaN inputs are reported too (and stay NaN)
+    an = a.clone(); an[3, 5] = float("nan")
+    with pytest.raises(ValueError):
+        G.split_planes(an)                                                # host packer: range-checked at once
+    with pytest.raises(ValueError):
+        G.split_planes(torch.tensor([1e5]))
+    # in-range work leaves the flag alone
+    p2 = G.plan_linear(M, torch.full((N, K), 0.5), None, device=gpu_device, split=True)
+    p2.run(A, out_h=out_h)
+    torch.cuda.synchronize()
+    _lib.check_overflow()
+    assert (G.join_planes(out_h.cpu()) - 800.0).abs().max() < 1e-3
+
+
+def test_split_small_magnitudes(gpu_device):
+    """The other end of the range: values whose hi would be an fp16 subnormal (|x| < 2^-14) are carried by the lo plane alone
+    (absolute error <= 2^-25 per element, csrc/device_math.h), so tiny activations neither flush to zero nor depend on how the
+    matrix cores treat fp16 subnormals."""
+    _lib.init()
+    _lib.lib().advh_split_overflow(1)
+    vals = torch.tensor([6.0e-5, 1.0e-5, 1.0e-6, 3.0e-8, 1.0e-9, -2.5e-7, 0.0, 6.2e-5])
+    s = G.split_planes(vals)
+    assert (s[0][vals.abs() < 2.0 ** -14] == 0).all()                     # hi plane is zero below 2^-14
+    assert (G.join_planes(s) - vals).abs().max() <= 2.0 ** -25
+    M, K, N = 128, 64, 32
+    g = torch.Generator().manual_seed(9)
+    a = torch.randn(M, K, generator=g) * 1e-6                             # every activation is "subnormal-range"
+    w = torch.randn(N, K, generator=g)
+    p = G.plan_linear(M, w, None, device=gpu_device, split=True)
+    out_f = torch.zeros(M, N, dtype=torch.float32, device=gpu_device)
+    out_h = torch.zeros(2, M, N, dtype=torch.float16, device=gpu_device)
+    p.run(G.split_planes(a).to(gpu_device), out_f=out_f, out_h=out_h)
+    ref = a.double() @ w.double().T
+    bound = K * 2.0 ** -25 * w.abs().max().item()                         # per-element absolute representation error, summed
+    assert (out_f.cpu().double() - ref).abs().max().item() <= bound
+    assert (G.join_planes(out_h.cpu()).double() - ref).abs().max().item() <= bound + 2.0 ** -25
+    assert ref.abs().max() > 1e-6                                         # the result itself is not flushed
+    torch.cuda.synchronize()
+    _lib.check_overflow()

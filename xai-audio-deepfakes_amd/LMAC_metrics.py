@@ -25,7 +25,9 @@ def get_model():
         m = ADDvisor()
         path = os.environ.get("ADDVISOR_UNET_CKPT")
         m.load_state_dict(torch.load(path, map_location="cpu") if path else syn.unet_weights())
-        _model = m.eval()
+        # The reference never calls .eval() (LMAC_metrics.py:18-26), so its BatchNorm layers use batch statistics; that is the
+        # ADDVISOR_BN_MODE=batch switch.  Default: eval-mode BatchNorm, as the streamlit study does.
+        _model = m.train() if m.bn_mode == "batch" else m.eval()
     return _model
 
 

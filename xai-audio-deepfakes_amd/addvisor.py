@@ -32,9 +32,45 @@ class ConvBlock(nn.Module):
         return self.block(x)
 
 
+class _BatchStatEngine:
+    """Inference with BATCH-statistics BatchNorm: what the reference's metrics script computes, because it never
+    calls ``model.eval()`` (LMAC_metrics.py:18-26: ``nn.BatchNorm2d`` in train mode normalises with the statistics of the
+    current batch and updates the running buffers, also under ``no_grad``).  Runs the training engine's forward
+    (advh_bn_stats / advh_bn_coef / advh_bn_apply) on device copies of the module's tensors and writes the updated running
+    statistics back into the module.  Same call shape as ``HipUNet`` (``forward(mag)``, ``precision``, ``flops``)."""
+
+    def __init__(self, module: "UNet", dev):
+        from addvisor_hip.unet_train import HipUNetTrain
+        self.module, self.dev = module, dev
+        self.tensors = {k: v.detach().to(dev, copy=True) for k, v in module.state_dict().items()}
+        self.engine = HipUNetTrain(self.tensors, dev)
+        self.precision = self.engine.precision
+
+    def forward(self, mag, H: int = 512, W=None):
+        mask = self.engine.forward(mag, H=H, W=W)
+        with torch.no_grad():                              # the reference's buffers move with every batch it sees
+            own = dict(self.module.named_buffers())
+            for k, v in self.tensors.items():
+                if k in own:
+                    own[k].copy_(v)
+        return mask
+
+    def flops(self, B, H, W):
+        ws = self.engine._workspace(B, H, W)
+        return sum(L["fwd"].flops for L in ws["layers"] if "fwd" in L) + 2.0 * B * (H // 2) * W * 32 * 15 + 2.0 * B * H * W * 32
+
+
 class UNet(nn.Module):
-    def __init__(self):
+    def __init__(self, bn_mode=None):
+        """``bn_mode`` (not in the reference's signature, ``UNet()``): how a module that is in ``train()`` mode normalises when
+        gradients are disabled -- "eval" (default, or ``ADDVISOR_BN_MODE``): running statistics, BatchNorm folded into the
+        convolutions (what ``streamlit_controlled_study.py:41`` does by calling ``.eval()``); "batch": batch statistics +
+        running-buffer updates, i.e. the reference's metrics script exactly as written (LMAC_metrics.py:18-26 never calls
+        ``.eval()``).  A module in ``eval()`` mode always uses its running statistics."""
         super().__init__()
+        self.bn_mode = (bn_mode or os.environ.get("ADDVISOR_BN_MODE", "eval")).lower()
+        if self.bn_mode not in ("eval", "batch"):
+            raise ValueError("bn_mode must be 'eval' or 'batch'")
         self.e1 = ConvBlock(1, 32, kernel_size=(5, 3), stride=(2, 1), padding=(2, 1))
         self.e2 = ConvBlock(32, 64, kernel_size=(5, 3), stride=(2, 1), padding=(2, 1))
         self.e3 = ConvBlock(64, 128, stride=(2, 2))
@@ -60,9 +96,15 @@ class UNet(nn.Module):
         return super().load_state_dict(state_dict, strict=strict, **kw)
 
     def _engine(self, dev):
-        if self._hip is None:
-            from addvisor_hip.unet import HipUNet
-            self._hip = HipUNet({k: v.detach().cpu() for k, v in self.state_dict().items()}, dev)
+        """The inference engine of the module's current state: eval-mode BatchNorm folded into the packed weights, or -- a
+        module left in train() mode with ``bn_mode="batch"`` -- the batch-statistics forward."""
+        batch = self.training and self.bn_mode == "batch"
+        if self._hip is None or isinstance(self._hip, _BatchStatEngine) != batch:
+            if batch:
+                self._hip = _BatchStatEngine(self, dev)
+            else:
+                from addvisor_hip.unet import HipUNet
+                self._hip = HipUNet({k: v.detach().cpu() for k, v in self.state_dict().items()}, dev)
         return self._hip
 
     def forward(self, x):
@@ -88,9 +130,10 @@ class UNet(nn.Module):
                                    "there is no CPU / eager-PyTorch path")
             mask = self._forward_hip_train(x4.to(pdev, torch.float32))
             return mask[:, 0] if squeeze else mask
-        if self.training and not self._warned:
+        if self.training and self.bn_mode != "batch" and not self._warned:
             warnings.warn("UNet is in training mode but gradients are disabled; the HIP path uses eval-mode "
-                          "BatchNorm (running statistics), see SURVEY.md D5", stacklevel=2)
+                          "BatchNorm (running statistics); UNet(bn_mode='batch') / ADDVISOR_BN_MODE=batch gives the "
+                          "batch-statistics forward of the reference's metrics script, see SURVEY.md D5", stacklevel=2)
             self._warned = True
         mask = self._engine(dev).forward(x4[:, 0].to(dev, torch.float32).contiguous(), H=Fq, W=Tq)
         return mask if squeeze else mask[:, None]

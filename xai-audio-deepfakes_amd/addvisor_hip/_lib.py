@@ -111,6 +111,7 @@ SIGNATURES = {
     "advh_unet_head_bwd_split": (_i, [_p, _p, _p, _f, _i64, _p, _p, _i64, _p]),
     "advh_unet_head_wgrad_split": (_i, [_p, _p, _i64, _i64, _p, _p, _p]),
     "advh_unet_stem_wgrad_split": (_i, [_p, _i64, _i, _i, _i, _i, _i, _p, _i, _i, _p, _p, _p]),
+    "advh_split_overflow": (_i, [_i]),
     "advh_layernorm_bwd_split": (_i, [_p, _i, _i64, _p, _i, _i64, _p, _p, _i, _p, _p, _i64, _p, _p, _i64, _i, _i, _f, _i, _i, _p]),
     "advh_attention_bwd_split": (_i, [_p, _i64, _p, _i64, _p, _i64, _i, _i, _i, _i, _p]),
     "advh_pool_logreg_bwd_split": (_i, [_p, _p, _p, _p, _i64, _i, _i, _i, _p]),
@@ -138,9 +139,23 @@ def lib() -> C.CDLL:
     return _lib
 
 
+class SplitRangeError(AdvhError, FloatingPointError):
+    """A kernel of the fp32-class mode met a value outside the split format's range (|x| > 65504, or NaN)."""
+
+
+def check_overflow(what: str = "") -> None:
+    """Raise if the library's sticky range flag is set (and clear it).  The flag lives in host-mapped memory: reading it does
+    not synchronise, so it reports kernels that have ALREADY run -- call after a synchronisation point for a definite answer."""
+    if _lib is not None and _lib.advh_split_overflow(1):
+        raise SplitRangeError((what + ": " if what else "") + "a value left the fp32-class format's range (|x| > 65504 between two "
+                              "matrix products, or NaN): the split planes saturated.  Scale the input / weights, or run precision='f16' "
+                              "diagnostics; the reference's fp32 has no such limit (include/addvisor_hip.h, advh_split_overflow)")
+
+
 def check(rc: int, what: str) -> None:
     if rc != 0:
         raise AdvhError(f"{what}: {ERRORS.get(rc, rc)}")
+    check_overflow(what)
 
 
 _inited = set()

@@ -52,7 +52,9 @@ class HipAttribution:
         # the planes between the dgrad GEMMs have fp16's exponent range: an overflow (|scaled gradient| > 65504 somewhere in the
         # chain) surfaces as inf / NaN in the input gradient and in every sum over path points.  One flag read per attribution:
         # raise instead of handing back a poisoned attribution map.
-        if not bool(torch.isfinite(out).all()):
+        finite = bool(torch.isfinite(out).all())             # synchronises: every kernel of the chain has run
+        _lib.check_overflow("attribution")                   # fp32-class chain: saturated planes raise SplitRangeError (a FloatingPointError)
+        if not finite:
             raise FloatingPointError(f"non-finite attribution: the gradient chain overflowed at loss_scale={self.loss_scale:g} "
                                      "(lower HipAttribution.loss_scale by a power of two)")
         return out

@@ -129,6 +129,11 @@ def split_planes(x: torch.Tensor) -> torch.Tensor:
     """Host-side packer of the split format (csrc/device_math.h): ``x`` (any float dtype) -> fp16 ``[2, *x.shape]`` with
     ``x = hi + lo * 2**-11``; computed in fp64, so an fp64 source (BatchNorm-folded / composed weights) keeps ~22 bits."""
     x64 = x.detach().to(torch.float64)
+    # range of the format: |x| <= 65504 (hi is an fp16).  Weights / host tensors outside it are a caller error, reported here
+    # rather than as saturated planes on the device (csrc/device_math.h split_f32 saturates and raises the sticky flag).
+    bad = ~(x64.abs() <= 65504.0)
+    if bool(bad.any()):
+        raise ValueError(f"split format: {int(bad.sum())} value(s) outside |x| <= 65504 (or NaN); max |x| = {float(x64.abs().nan_to_num(float('inf')).max()):g}")
     hi = x64.to(torch.float16)
     hi = torch.where(x64.abs() < 2.0 ** -14, torch.zeros_like(hi), hi)
     lo = ((x64 - hi.to(torch.float64)) * 2048.0).to(torch.float16)

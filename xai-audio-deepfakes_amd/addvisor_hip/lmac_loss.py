@@ -18,7 +18,7 @@ from __future__ import annotations
 
 import torch
 
-from . import ops
+from . import _lib, ops
 from .embedder_grad import EmbedderGrad
 
 
@@ -64,15 +64,27 @@ class _LMACTerms(torch.autograd.Function):
             # gradient.  Back the power-of-two scale off (exact), keep it for the following steps and redo this backward
             # rather than hand a poisoned gradient to the optimiser.  A NaN that is not an overflow (bad input) fails at once
             # when the forward logits are already non-finite.
-            g = eg.backward(scaler.scale, seed=seed)                        # dL/d wave, [2B, length]
-            ok_fwd, ok = torch.stack([torch.isfinite(logits).all(), torch.isfinite(g).all()]).tolist()   # ONE read for both flags
+            def attempt():
+                """dL/d wave at the current scale and whether it is usable.  An overflow shows up as inf / NaN (fp16 chain) or
+                as the split format's sticky range flag (fp32-class chain: its planes saturate) -- possibly as a SplitRangeError
+                out of a later launch of the same chain."""
+                try:
+                    gg = eg.backward(scaler.scale, seed=seed)               # [2B, length]
+                    flags = torch.stack([torch.isfinite(logits).all(), torch.isfinite(gg).all()]).tolist()   # ONE read for both flags (synchronises)
+                    _lib.check_overflow("LMAC loss backward")
+                    return gg, flags[0], flags[1]
+                except _lib.SplitRangeError:
+                    torch.cuda.synchronize()
+                    _lib.lib().advh_split_overflow(1)
+                    return None, bool(torch.isfinite(logits).all()), False
+
+            g, ok_fwd, ok = attempt()
             if not ok_fwd:
                 raise FloatingPointError("LMAC loss: non-finite classifier logits in the forward pass (bad input or weights)")
             while not ok:
                 if not scaler.backoff():
                     raise FloatingPointError(f"LMAC loss backward: non-finite input gradient at every loss scale down to {scaler.scale:g}")
-                g = eg.backward(scaler.scale, seed=seed)
-                ok = bool(torch.isfinite(g).all())
+                g, _, ok = attempt()
             scaler.good()
             g_in = ops.istft_masked_bwd(g[:B], mag, phase, m, 0, domain="linear", hop=hop, win=win)
             g_out = ops.istft_masked_bwd(g[B:], mag, phase, m, 1, domain="linear", hop=hop, win=win)

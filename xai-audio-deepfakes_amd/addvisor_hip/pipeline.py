@@ -177,8 +177,8 @@ def gather_probabilities(local: torch.Tensor, n_total: int, group=None) -> torch
     """``local [n_r, 3]`` (p, theta, p_out of this rank's block) -> ``[n_total, 3]`` in clip order on every
     rank.  One all_gather of equal-sized, zero-padded blocks (RCCL on GPUs, gloo in the CPU tests)."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        return local
+    if not (dist.is_available() and dist.is_initialized()):
+        return local                                             # no process group: single process (a one-rank group still runs the collective)
     world = dist.get_world_size(group)
     per = -(-n_total // world)
     dev = local.device

@@ -731,3 +731,5 @@ extern "C" int advh_attention_split(const void* qkv, int64_t qkv_lo, void* ctx, 
 #undef ATTX
     return ADVH_LAUNCH_CHECK();
 }
+
+ADVH_SPLIT_FLAG_SETTER(advh_split_flag_attention)

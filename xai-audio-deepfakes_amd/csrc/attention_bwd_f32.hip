@@ -323,3 +323,5 @@ extern "C" int advh_attention_bwd_split(const void* qkv, int64_t qkv_lo, const v
 #undef ATB
     return ADVH_EUNSUPPORTED;
 }
+
+ADVH_SPLIT_FLAG_SETTER(advh_split_flag_attention_bwd_f32)

@@ -589,3 +589,5 @@ extern "C" int advh_scale_rows(const float* x, int x_rows, const float* alpha, f
                        accumulate, x_rows);
     return ADVH_LAUNCH_CHECK();
 }
+
+ADVH_SPLIT_FLAG_SETTER(advh_split_flag_backward)

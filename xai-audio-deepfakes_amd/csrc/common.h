@@ -6,6 +6,17 @@
 // Per-module one-time initialisation (dynamic-LDS attributes); defined in gemm.hip.
 int advh_init_rest();
 int advh_init_attention();   // attention.hip
+// per-translation-unit setters of the split-format range flag pointer (csrc/device_math.h: ADVH_SPLIT_FLAG_SETTER)
+int advh_split_flag_attention(int* flag);
+int advh_split_flag_attention_bwd_f32(int* flag);
+int advh_split_flag_backward(int* flag);
+int advh_split_flag_frontend(int* flag);
+int advh_split_flag_frontend_bwd(int* flag);
+int advh_split_flag_gemm(int* flag);
+int advh_split_flag_hifigan(int* flag);
+int advh_split_flag_rowops(int* flag);
+int advh_split_flag_unet_misc(int* flag);
+int advh_split_flag_unet_train(int* flag);
 
 // Raise a kernel's dynamic-LDS limit to `bytes` once per (kernel, DEVICE): the attribute belongs to the device's copy of
 // the code object, and one process may drive several GPUs (a per-process "done" flag left the second device at 64 KiB).

@@ -34,13 +34,33 @@ __device__ __forceinline__ float gelu_fast(float x) { return 0.5f * x * (1.f + f
 // (absolute error there <= 2^-25 = 3e-8), so the result does not depend on how the matrix cores treat fp16 subnormals.  A product of two split
 // values is x*w = xh*wh + (xh*wl + xl*wh) * 2^-11 (+ xl*wl * 2^-22, dropped: <= 2^-22 relative): three fp16 MFMAs with fp32
 // accumulation, the cross terms in their own accumulator.  Every fp16 x fp16 product is exact in fp32.
-constexpr float SPLIT_LO_SCALE = 2048.f, SPLIT_LO_INV = 1.f / 2048.f;
+// RANGE: hi is an fp16, so the format covers |x| <= 65504 (fp16's largest finite value; the reference's fp32 reaches 3.4e38).
+// A value beyond that SATURATES (hi = +-65504, lo = the clamped remainder: x up to +-65535.98 is still exact) instead of
+// turning into inf / NaN downstream, and raises the library's sticky range flag -- one host-mapped word the device writes
+// and the host reads without synchronising (advh_split_overflow; the Python binding turns it into an error at its next call).
+// NaN inputs stay NaN and raise the flag too.
+constexpr float SPLIT_LO_SCALE = 2048.f, SPLIT_LO_INV = 1.f / 2048.f, SPLIT_MAX = 65504.f;
+static __device__ int* g_split_flag = nullptr;       // this translation unit's copy of the flag pointer (set by advh_init)
 __device__ __forceinline__ void split_f32(float x, _Float16& hi, _Float16& lo) {
+    if (!(fabsf(x) <= SPLIT_MAX)) {                  // out of range, or NaN (rare path)
+        if (g_split_flag) *(volatile int*)g_split_flag = 1;
+        if (x == x) {
+            const float h = copysignf(SPLIT_MAX, x);
+            hi = (_Float16)h;
+            lo = (_Float16)fminf(fmaxf((x - h) * SPLIT_LO_SCALE, -SPLIT_MAX), SPLIT_MAX);
+            return;
+        }
+    }
     _Float16 h = (_Float16)x;
     if (fabsf(x) < 6.103515625e-05f) h = (_Float16)0.f;
     hi = h;
     lo = (_Float16)((x - (float)h) * SPLIT_LO_SCALE);
 }
+// defines this translation unit's setter of g_split_flag (called by advh_init on every device it initialises)
+#define ADVH_SPLIT_FLAG_SETTER(name)                                                                                       \
+    int name(int* flag) {                                                                                                  \
+        return hipMemcpyToSymbol(HIP_SYMBOL(advh::g_split_flag), &flag, sizeof(flag)) == hipSuccess ? ADVH_OK : ADVH_ELAUNCH; \
+    }
 __device__ __forceinline__ float join_f32(_Float16 hi, _Float16 lo) { return fmaf((float)lo, SPLIT_LO_INV, (float)hi); }
 
 // VW consecutive fp16 elements at base + o: plain fp16 (lo_off == 0) or the hi / lo plane pair (lo plane lo_off elements

@@ -223,3 +223,5 @@ extern "C" int advh_w2v2_frontend_split(const float* wave, int64_t wave_stride, 
     if (out_lo <= 0 || out_lo % 8) return ADVH_EINVAL;
     return frontend_launch(wave, wave_stride, n_in, B, L, w0, bias0, gamma, beta, mode, normalize, stats_ws, norm_ws, mr_ws, out, out_lo, T0, P0, C0, stream);
 }
+
+ADVH_SPLIT_FLAG_SETTER(advh_split_flag_frontend)

@@ -200,3 +200,5 @@ extern "C" int advh_wave_bwd(const float* g, const float* wave, int64_t wave_str
                        (const float2*)stats_ws, (const float2*)part_ws, nt, normalize, out_scale, dx, (long)dx_stride);
     return ADVH_LAUNCH_CHECK();
 }
+
+ADVH_SPLIT_FLAG_SETTER(advh_split_flag_frontend_bwd)

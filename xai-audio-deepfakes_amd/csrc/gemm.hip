@@ -1627,3 +1627,5 @@ extern "C" int advh_gemm_f16(const advh_gemm_desc* d, int tile, advh_stream_t st
         default: return ADVH_EINVAL;
     }
 }
+
+ADVH_SPLIT_FLAG_SETTER(advh_split_flag_gemm)

@@ -194,3 +194,5 @@ extern "C" int advh_mel_log(const float* mag, const float* fb, float* out, int B
     hipLaunchKernelGGL(mel_log_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, mag, fb, out, F, T, n_mels, total);
     return ADVH_LAUNCH_CHECK();
 }
+
+ADVH_SPLIT_FLAG_SETTER(advh_split_flag_hifigan)

@@ -274,3 +274,5 @@ extern "C" int advh_pool_logreg(const float* h, const float* coef, float interce
         hipLaunchKernelGGL(pool_logreg_kernel, dim3(B), dim3(256), 0, s, h, coef, intercept, logit, prob, pooled, T, H);
     return ADVH_LAUNCH_CHECK();
 }
+
+ADVH_SPLIT_FLAG_SETTER(advh_split_flag_rowops)

@@ -426,6 +426,8 @@ extern "C" const char* advh_version(void) { return "addvisor_hip 0.1 (gfx950, wa
 extern "C" int advh_debug_stamps(long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(long long) * 16) == hipSuccess ? ADVH_OK : ADVH_ELAUNCH; }
 #endif
 
+static int* g_split_flag_host = nullptr;       // hipHostMallocMapped: device-written, host-read without a synchronisation
+
 extern "C" int advh_set_option(const char* name, int value) {
     if (!name) return ADVH_EINVAL;
     if (!strcmp(name, "stft_frames_per_workgroup")) {
@@ -460,8 +462,25 @@ extern "C" int advh_init(void) {
     if (rc != ADVH_OK) return rc;
     rc = advh_init_attention();
     if (rc != ADVH_OK) return rc;
+    // the split format's sticky range flag: ONE host-mapped word per process, written by the kernels of every device
+    if (!g_split_flag_host) {
+        if (hipHostMalloc((void**)&g_split_flag_host, sizeof(int), hipHostMallocMapped) != hipSuccess) return ADVH_ELAUNCH;
+        *g_split_flag_host = 0;
+    }
+    int* dflag = nullptr;
+    if (hipHostGetDevicePointer((void**)&dflag, g_split_flag_host, 0) != hipSuccess) return ADVH_ELAUNCH;
+    int (*const setters[])(int*) = {advh_split_flag_attention, advh_split_flag_attention_bwd_f32, advh_split_flag_backward, advh_split_flag_frontend, advh_split_flag_frontend_bwd, advh_split_flag_gemm, advh_split_flag_hifigan, advh_split_flag_rowops, advh_split_flag_unet_misc, advh_split_flag_unet_train};
+    for (auto set : setters)
+        if ((rc = set(dflag)) != ADVH_OK) return rc;
     g_init_done[dev] = true;
     return ADVH_OK;
+}
+
+extern "C" int advh_split_overflow(int reset) {
+    if (!g_split_flag_host) return 0;
+    const int v = *(volatile int*)g_split_flag_host;
+    if (reset) *(volatile int*)g_split_flag_host = 0;
+    return v != 0;
 }
 
 static int check_frame_args(int B, int T, int L, int hop, int win) {

@@ -150,3 +150,5 @@ extern "C" int advh_unet_head_split(const void* y, int64_t y_lo, int B, int H, i
     if (y_lo <= 0 || y_lo % 8) return ADVH_EINVAL;
     return head_launch(y, y_lo, B, H, W, PH, PW, wgt, bias, mask, logits, stream);
 }
+
+ADVH_SPLIT_FLAG_SETTER(advh_split_flag_unet_misc)

@@ -500,3 +500,5 @@ extern "C" int advh_unet_head_bwd_split(const float* dmask, const float* mask, c
     if (dy_lo <= 0 || dy_lo % 8) return ADVH_EINVAL;
     return head_bwd_launch(dmask, mask, w32, scale, total, dlogit, dy1, 0, dy_lo, stream);
 }
+
+ADVH_SPLIT_FLAG_SETTER(advh_split_flag_unet_train)
