@@ -121,12 +121,8 @@ int advh_istft_masked_bwd(const float* g_wave, int64_t g_stride, const float* ma
  * operands by a_sZ (chunks), w_sZ (elements), bias_sZ, o_sZ.                                     */
 enum { ADVH_ACT_NONE = 0, ADVH_ACT_GELU = 1, ADVH_ACT_LEAKY = 2 };
 enum { ADVH_TILE_AUTO = 0, ADVH_TILE_128x128 = 1, ADVH_TILE_256x64 = 2, ADVH_TILE_256x32 = 3,
-       ADVH_TILE_256x256 = 4, ADVH_TILE_256x128 = 5 /* 512-thread, LDS ring */,
-       ADVH_TILE_256x128_W4 = 6, ADVH_TILE_128x256_W4 = 7 /* 256-thread, 128x64 / 64x128 wave tiles */,
-       ADVH_TILE_256x256_RING = 8 /* 512-thread, 32-deep K-tiles in a 4-stage LDS ring */,
-       ADVH_TILE_256x128_W8 = 9, ADVH_TILE_128x256_W8 = 10 /* 512-thread single-buffer kernel, 64x64 wave tiles, 2 workgroups per CU */,
-       ADVH_TILE_256x256_W4 = 12 /* 256-thread 2-stage ring, 128x128 wave tiles, one wavefront per SIMD */,
-       ADVH_TILE_256x128_PERSIST = 11 /* persistent 3-stage ring: one workgroup per CU walks tiles, K-steps of consecutive tiles form one DMA stream */ };
+       ADVH_TILE_256x128_W8 = 9, ADVH_TILE_128x256_W8 = 10 /* 512-thread instances of the same single-buffer kernel, 64x64 wave tiles, 2 workgroups
+                                                               per CU: tuner candidates (they win one K = 4096 shape); fp16 operands only */ };
 
 typedef struct advh_gemm_desc {
     const void* A0;       /* fp16 source 0                                   */

@@ -153,7 +153,7 @@ def test_conv1d_line_tile(gpu_device, Cn, k, d, B, T):
         close(o1, o3.cpu())
 
 
-@pytest.mark.parametrize("tile", [G.TILE_256x128_PERSIST, G.TILE_256x128, G.TILE_256x256, G.TILE_128x256_W8, G.TILE_256x128_W8, G.TILE_256x256_W4])
+@pytest.mark.parametrize("tile", [G.TILE_128x256_W8, G.TILE_256x128_W8])
 def test_alternative_tiles_are_bit_identical(gpu_device, tile):
     """Every tile variant walks K in the same order with fp32 accumulators, so all of them must reproduce the default
     128x128 tile bit for bit -- on a plain GEMM with M / N tails, a gathered Conv2d with two sources, and a grid-z

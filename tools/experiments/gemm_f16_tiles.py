@@ -4,7 +4,7 @@ sys.path.insert(0, "xai-audio-deepfakes_amd")
 from addvisor_hip import gemm as G, _lib
 _lib.init()
 dev = torch.device("cuda:0")
-TILES = [G.TILE_128x128, G.TILE_256x128_W8, G.TILE_128x256_W8, G.TILE_256x128, G.TILE_256x256, G.TILE_256x128_W4, G.TILE_128x256_W4, G.TILE_256x128_PERSIST]
+TILES = [G.TILE_128x128, G.TILE_256x128_W8, G.TILE_128x256_W8]    # the ring / pipelined / persistent variants this script compared in round 2 (profiles/r02_f16_tiles.txt) were removed in round 3
 
 
 def bench(name, M, K, N):

@@ -12,7 +12,7 @@ def bench(name, M, K, N, lda=None):
     out = torch.empty(M, N, dtype=torch.float16, device=dev)
     res = []
     ref = None
-    for tile in (G.TILE_128x128, G.TILE_256x128_W4, G.TILE_128x256_W4, G.TILE_128x256_W8):
+    for tile in (G.TILE_128x128, G.TILE_256x128_W8, G.TILE_128x256_W8):
         if N < G.TILE_BN[tile] // 2: continue
         p.tile = tile
         out.zero_()

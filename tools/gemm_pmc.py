@@ -4,7 +4,7 @@ from addvisor_hip import gemm as G, _lib
 _lib.init()
 dev = torch.device("cuda:0")
 split = sys.argv[1].startswith("x3:")
-tile = {"128": G.TILE_128x128, "256": G.TILE_256x256, "256x128": G.TILE_256x128}[sys.argv[1].replace("x3:", "")]
+tile = {"128": G.TILE_128x128, "256x128": G.TILE_256x128_W8, "128x256": G.TILE_128x256_W8}[sys.argv[1].replace("x3:", "")]
 M, K, N = (int(v) for v in sys.argv[2:5])
 lda = int(sys.argv[5]) if len(sys.argv) > 5 else None
 g = torch.Generator().manual_seed(0)

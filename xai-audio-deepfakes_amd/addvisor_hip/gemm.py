@@ -26,17 +26,13 @@ def packed_row_channel(rows: int) -> np.ndarray:
     """Output channel carried by packed weight row R in the wide layout (``advh_gemm_desc.wide``)."""
     R = np.arange(rows)
     return ((R >> 5) << 5) + (((R >> 2) & 3) << 3) + (((R >> 4) & 1) << 2) + (R & 3)
-TILE_AUTO, TILE_128x128, TILE_256x64, TILE_256x32, TILE_256x256, TILE_256x128, TILE_256x128_W4, TILE_128x256_W4, TILE_256x256_RING = 0, 1, 2, 3, 4, 5, 6, 7, 8
-TILE_256x128_W8, TILE_128x256_W8, TILE_256x128_PERSIST, TILE_256x256_W4 = 9, 10, 11, 12
-TILE_BN = {TILE_128x128: 128, TILE_256x64: 64, TILE_256x32: 32, TILE_256x256: 256, TILE_256x128: 128, TILE_256x128_W4: 128, TILE_128x256_W4: 256, TILE_256x256_RING: 256,
-           TILE_256x128_W8: 128, TILE_128x256_W8: 256, TILE_256x128_PERSIST: 128, TILE_256x256_W4: 256}
-TILE_NAMES = {TILE_128x128: "128x128", TILE_256x64: "256x64", TILE_256x32: "256x32", TILE_256x256: "256x256p", TILE_256x128: "256x128p",
-              TILE_256x128_W4: "256x128w4", TILE_128x256_W4: "128x256w4", TILE_256x256_RING: "256x256r",
-              TILE_256x128_W8: "256x128w8", TILE_128x256_W8: "128x256w8", TILE_256x128_PERSIST: "256x128ps", TILE_256x256_W4: "256x256w4"}
+TILE_AUTO, TILE_128x128, TILE_256x64, TILE_256x32 = 0, 1, 2, 3
+TILE_256x128_W8, TILE_128x256_W8 = 9, 10
+TILE_BN = {TILE_128x128: 128, TILE_256x64: 64, TILE_256x32: 32, TILE_256x128_W8: 128, TILE_128x256_W8: 256}
+TILE_NAMES = {TILE_128x128: "128x128", TILE_256x64: "256x64", TILE_256x32: "256x32", TILE_256x128_W8: "256x128w8", TILE_128x256_W8: "128x256w8"}
 # device symbol (as rocprofv3 prints it) of the kernels the live profile covers
 TILE_KERNELS = {TILE_128x128: "gemm_f16_kernel<128, 128, 2, 2, 4>", TILE_128x256_W8: "gemm_f16_kernel<128, 256, 2, 4, 3>",
-                TILE_256x128_W8: "gemm_f16_kernel<256, 128, 4, 2, 3>", TILE_256x256: "gemm_f16_pipe_kernel<256, 256, 2, 4, 2>",
-                TILE_256x128: "gemm_f16_pipe_kernel<256, 128, 4, 2, 3>", TILE_256x128_PERSIST: "gemm_f16_persist_kernel<256, 128, 4, 2>"}
+                TILE_256x128_W8: "gemm_f16_kernel<256, 128, 4, 2, 3>"}
 
 
 class GemmDesc(C.Structure):
@@ -374,9 +370,7 @@ class GemmPlan:
 
 
 def _tune(self, d, stream):
-    cands = [TILE_128x128, TILE_128x256_W8, TILE_256x128_W8, TILE_256x256] if (self.desc.N > 64 and not self.split) else [self.tile]
-    if self.desc.nz_lo > 1 or self.desc.z_inner:
-        cands = [c for c in cands if c != TILE_256x256]       # the two-level batch lives in gemm_f16_kernel only
+    cands = [TILE_128x128, TILE_128x256_W8, TILE_256x128_W8] if (self.desc.N > 64 and not self.split) else [self.tile]
     best, best_ms = self.tile, None
     if len(cands) > 1:
         for t in cands:

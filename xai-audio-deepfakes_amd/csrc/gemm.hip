@@ -40,10 +40,6 @@ __device__ long long g_kstep[8];               // wave 0 of the mid-grid workgro
 __device__ long long g_wg_rec[4 * 16384];   // per workgroup of the last x3 launch: start, K loop end, end (100 MHz ticks), HW_ID | XCC_ID << 32
 #endif
 
-// ds_read_b128 the compiler does not track (see the pipelined kernel) and the matching counted wait
-#define DS_READ128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
-#define LGKM_WAIT(n) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(n) : "memory")
-
 __device__ __forceinline__ float apply_act(float x, int act, float slope) {
     if (act == ADVH_ACT_GELU) return gelu_fast(x);
     if (act == ADVH_ACT_LEAKY) return x > 0.f ? x : slope * x;
@@ -1081,496 +1077,12 @@ static int launch_x3(const advh_gemm_desc& d, hipStream_t s) {
     return ADVH_LAUNCH_CHECK();
 }
 
-// ---------------------------------------------------------------------------------------------------
-// Large-tile variant: 512 threads = 8 wavefronts (2 per SIMD), BM x BN x 64 tile with a 2-stage LDS ring
-// (dynamic LDS, up to 128 KiB => one workgroup per CU).  The global->LDS DMA of K-tile t+1 is issued
-// right after the barrier that publishes K-tile t and stays in flight under the 64 MFMAs per wavefront of
-// tile t; one barrier per K-step.  Wave tile (BM/WM) x (BN/WN) = 128 x 64 for 256 x 256: 24 ds_read_b128
-// feed 64 MFMAs (the 128 x 128 kernel needs 16 per 32), which is what lifts the LDS-read bound.
-template <int BM, int BN, int WM, int WN, int STAGES>
-__global__ __launch_bounds__(64 * WM * WN) void gemm_f16_pipe_kernel(const advh_gemm_desc p) {
-    constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 16, NI = TN / 16;
-    constexpr int NT = 64 * WM * WN, RPP = NT / 8;  // threads; tile rows covered by one loader pass
-    constexpr int NA = BM / RPP, NB = BN / RPP;     // 16-byte chunks per thread per K-step
-    constexpr int STAGE = (BM + BN) * BK * 2;
-    static_assert(WM * WN == 8 || WM * WN == 4, "8 wavefronts (2 per SIMD) or 4 (one per SIMD, 128 x 128 wave tiles)");
-    extern __shared__ __attribute__((aligned(16))) char dsmem[];
-
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int wm = wv / WN, wn = wv % WN;
-    const int tilesN = (p.N + BN - 1) / BN;
-    const int nwg = gridDim.x;
-    int id = blockIdx.x;
-    {
-        const int q8 = nwg / 8, r8 = nwg % 8, xcd = id % 8;
-        id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + id / 8;
-    }
-    const int tile_n = id % tilesN, tile_m = id / tilesN;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int z = blockIdx.z;
-    const _Float16* A0 = (const _Float16*)p.A0 + p.a_sZ[0] * z * 8;
-    const _Float16* A1 = (const _Float16*)p.A1 + p.a_sZ[1] * z * 8;
-    const _Float16* Wp = (const _Float16*)p.W + p.w_sZ * z;
-
-    const int ldrow = tid >> 3;                          // + RPP*i
-    const int q = (tid & 7) ^ (ldrow & 7);
-    long safe0 = (long)p.h0 * p.a_sH[0] + (long)p.w0 * p.a_sW[0] + p.a_c0[0];
-    long safe1 = (long)p.h0 * p.a_sH[1] + (long)p.w0 * p.a_sW[1] + p.a_c0[1];
-    unsigned rb0[NA], rb1[NA];
-    const RowDecomp rd(p.Wg, p.Hg);
-#pragma unroll
-    for (int i = 0; i < NA; ++i) {
-        unsigned m = m0 + ldrow + RPP * i;
-        unsigned w, h, b;
-        rd(m, b, h, w);
-        bool ok = m < (unsigned)p.M && (int)h >= p.h0 && (int)h < p.h1 && (int)w >= p.w0 && (int)w < p.w1;
-        long r0 = ok ? (long)b * p.a_sB[0] + (long)h * p.a_sH[0] + (long)w * p.a_sW[0] + p.a_c0[0] : safe0;
-        long r1 = ok ? (long)b * p.a_sB[1] + (long)h * p.a_sH[1] + (long)w * p.a_sW[1] + p.a_c0[1] : safe1;
-        rb0[i] = (unsigned)r0;
-        rb1[i] = (unsigned)r1;
-    }
-    const _Float16* wrow[NB];
-#pragma unroll
-    for (int i = 0; i < NB; ++i) wrow[i] = Wp + (long)(n0 + ldrow + RPP * i) * (p.w_ld ? p.w_ld : (long)p.Ktot) + q * 8;
-
-    const int fr = lane & 15, fq = lane >> 4;
-    int offA[2], offB[2];
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-        int c = (kk * 4 + fq) ^ (fr & 7);
-        offA[kk] = ((wm * TM + fr) * 8 + c) * 16;
-        offB[kk] = BM * BK * 2 + ((wn * TN + fr) * 8 + c) * 16;
-    }
-    const unsigned lds0 = (unsigned)(unsigned long)LDS_PTR(dsmem);
-    const unsigned uoffA[2] = {(unsigned)offA[0], (unsigned)offA[1]}, uoffB[2] = {(unsigned)offB[0], (unsigned)offB[1]};
-
-    f32x4 acc[NI][MI];
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int nk = p.Ktot / BK;
-    const int* ktab = p.ktab;
-    // one 16-byte-per-lane DMA piece `i` (0 <= i < NA + NB) of K-tile kt; kq = its A chunk offset
-    auto issue_piece = [&](int kt, int kq, int i) {
-        char* st = dsmem + (kt % STAGES) * STAGE;
-        if (i < NA) {
-            const bool s1 = kq < 0;
-            const unsigned ko = (unsigned)kq & 0x7fffffffu;
-            const _Float16* g = (s1 ? A1 : A0) + ((unsigned long)((s1 ? rb1[i] : rb0[i]) + ko)) * 8;
-            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(g), LDS_PTR(st + (wv * 64 + NT * i) * 16), 16, 0, 0);
-        } else {
-            const int j = i - NA;
-            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(wrow[j] + kt * BK),
-                                             LDS_PTR(st + BM * BK * 2 + (wv * 64 + NT * j) * 16), 16, 0, 0);
-        }
-    };
-    auto tile_kq = [&](int kt) { return p.ktab_identity ? kt * 8 + q : ktab[kt * 8 + q]; };
-    auto issue = [&](int kt) {
-        const int kq = tile_kq(kt);
-#pragma unroll
-        for (int i = 0; i < NA + NB; ++i) issue_piece(kt, kq, i);
-    };
-    // prologue: STAGES-1 tiles in flight
-#pragma unroll
-    for (int t = 0; t < STAGES - 1; ++t)
-        if (t < nk) issue(t);
-    for (int kt = 0; kt < nk; ++kt) {
-        // tile kt landed for this wavefront: at most the STAGES-2 younger tiles may stay in flight
-        if (STAGES == 2 || kt + 1 >= nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (STAGES == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + NB) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (NA + NB)) : "memory");
-        __builtin_amdgcn_s_barrier();                          // ... for every wavefront; stage (kt-1)%STAGES is free
-        // the DMA of tile kt+STAGES-1 is issued piecewise between the MFMA groups below (a wavefront pays ~100
-        // cycles of issue per LDS-DMA piece: spread out, they overlap the partner wavefront's MFMAs)
-        const bool more = kt + STAGES - 1 < nk;
-        const int kq_next = more ? tile_kq(kt + STAGES - 1) : 0;
-        // Fragment software pipeline with hand-counted LDS waits.  The A fragments of m-pair g+1 (and, at the end
-        // of a 32-deep half, the next half's B fragments) are requested before the 2*NI MFMAs of m-pair g issue.
-        // hipcc waits lgkmcnt(0) at every first use, which would also wait for the reads just issued for the NEXT
-        // group; the ds_reads are therefore inline asm (invisible to its scoreboard) and each group waits with the
-        // exact count of younger reads allowed to stay in flight (cdna_hip_programming.md §5.7 form (iii)).
-        const unsigned sbase = lds0 + (kt % STAGES) * STAGE;
-        f16x8 b[2][NI], a[2][2];
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) DS_READ128(b[0][ni], sbase + uoffB[0], ni * 2048);
-#pragma unroll
-        for (int e = 0; e < 2; ++e) DS_READ128(a[0][e], sbase + uoffA[0], e * 2048);
-#pragma unroll
-        for (int step = 0; step < MI; ++step) {            // step = kk * (MI/2) + pair
-            const int kk = step / (MI / 2), pr = step % (MI / 2), cur = step & 1, nxt = cur ^ 1;
-            if (step + 1 < MI) {
-                const int kk2 = (step + 1) / (MI / 2), pr2 = (step + 1) % (MI / 2);
-#pragma unroll
-                for (int e = 0; e < 2; ++e) DS_READ128(a[nxt][e], sbase + uoffA[kk2], (2 * pr2 + e) * 2048);
-                if (pr2 == 0) {
-#pragma unroll
-                    for (int ni = 0; ni < NI; ++ni) DS_READ128(b[1][ni], sbase + uoffB[1], ni * 2048);
-                    LGKM_WAIT(2 + NI);
-                } else {
-                    LGKM_WAIT(2);
-                }
-            } else {
-                LGKM_WAIT(0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int e = 0; e < 2; ++e)
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni)
-                    acc[ni][2 * pr + e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[kk][ni], a[cur][e], acc[ni][2 * pr + e], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (more) {
-                constexpr int PER = (NA + NB + MI - 1) / MI;
-#pragma unroll
-                for (int i = step * PER; i < (step + 1) * PER && i < NA + NB; ++i) issue_piece(kt + STAGES - 1, kq_next, i);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-    gemm_epilogue<MI, NI>(p, acc, m0 + wm * TM, n0 + wn * TN, fr, fq, z);
-}
-
-template <int BM, int BN, int WM, int WN, int STAGES>
-static int launch_pipe(const advh_gemm_desc& d, hipStream_t s) {
-    const int tilesM = (d.M + BM - 1) / BM, tilesN = (d.N + BN - 1) / BN;
-    if (tilesN * BN > d.w_rows) return ADVH_EINVAL;
-    dim3 grid(tilesM * tilesN, 1, d.nz > 0 ? d.nz : 1);
-    hipLaunchKernelGGL((gemm_f16_pipe_kernel<BM, BN, WM, WN, STAGES>), grid, dim3(64 * WM * WN), STAGES * (BM + BN) * BK * 2, s, d);
-    return ADVH_LAUNCH_CHECK();
-}
-
-// ---------------------------------------------------------------------------------------------------
-// Persistent variant of the 3-stage pipe kernel: one workgroup per CU walks tiles t = blockIdx.x + i * gridDim.x
-// (grid-z batches folded into the walk) and treats the K-steps of all its tiles as ONE continuous stream through the
-// LDS ring: the DMA of the next tile's first K-steps is issued under the last MFMA groups of the current tile and
-// stays in flight during its epilogue, so the per-tile prologue (DMA latency) and epilogue (stores) that a
-// one-workgroup-per-CU tile otherwise exposes -- 12 K-steps per tile at K = 768 -- are overlapped.
-template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(512) void gemm_f16_persist_kernel(const advh_gemm_desc p, int tilesM, int tilesN) {
-    constexpr int STAGES = 3;
-    constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 16, NI = TN / 16;
-    constexpr int NA = BM / 64, NB = BN / 64;
-    constexpr int STAGE = (BM + BN) * BK * 2;
-    static_assert(WM * WN == 8, "8 wavefronts");
-    extern __shared__ __attribute__((aligned(16))) char dsmem[];
-
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int wm = wv / WN, wn = wv % WN;
-    const int per_z = tilesM * tilesN, total = per_z * (p.nz > 0 ? p.nz : 1);
-    const int nk = p.Ktot / BK;
-    const int* ktab = p.ktab;
-    const int ldrow = tid >> 3;
-    const int q = (tid & 7) ^ (ldrow & 7);
-    const long safe0 = (long)p.h0 * p.a_sH[0] + (long)p.w0 * p.a_sW[0] + p.a_c0[0];
-    const long safe1 = (long)p.h0 * p.a_sH[1] + (long)p.w0 * p.a_sW[1] + p.a_c0[1];
-    const RowDecomp rd(p.Wg, p.Hg);
-    const long wld = p.w_ld ? p.w_ld : (long)p.Ktot;
-
-    // tile t -> (m0, n0, z): XCD-aware bijection (workgroups of one XCD walk neighbouring tiles) + super-columns
-    auto locate = [&](int t, int& m0, int& n0, int& z) {
-        z = t / per_z;
-        int id = t - z * per_z;
-        const int q8 = per_z / 8, r8 = per_z % 8, xcd = id % 8;
-        id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + id / 8;
-        const int sc = (p.sc > 0 && p.sc < tilesN) ? p.sc : tilesN;
-        const int s = id / (tilesM * sc), rem = id - s * tilesM * sc;
-        const int wcols = min(sc, tilesN - s * sc);
-        const int tm = rem / wcols;
-        m0 = tm * BM;
-        n0 = (s * sc + rem - tm * wcols) * BN;
-    };
-
-    // ---- loader state of the tile whose K-steps are being issued
-    unsigned rb0[NA], rb1[NA];
-    const _Float16* wrow[NB];
-    const _Float16 *lA0 = nullptr, *lA1 = nullptr;
-    auto setup_loader = [&](int t) {
-        int m0, n0, z;
-        locate(t, m0, n0, z);
-        lA0 = (const _Float16*)p.A0 + p.a_sZ[0] * z * 8;
-        lA1 = (const _Float16*)p.A1 + p.a_sZ[1] * z * 8;
-        const _Float16* Wp = (const _Float16*)p.W + p.w_sZ * z;
-#pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            unsigned m = m0 + ldrow + 64 * i;
-            unsigned w, h, b;
-            rd(m, b, h, w);
-            bool ok = m < (unsigned)p.M && (int)h >= p.h0 && (int)h < p.h1 && (int)w >= p.w0 && (int)w < p.w1;
-            long r0 = ok ? (long)b * p.a_sB[0] + (long)h * p.a_sH[0] + (long)w * p.a_sW[0] + p.a_c0[0] : safe0;
-            long r1 = ok ? (long)b * p.a_sB[1] + (long)h * p.a_sH[1] + (long)w * p.a_sW[1] + p.a_c0[1] : safe1;
-            rb0[i] = (unsigned)r0;
-            rb1[i] = (unsigned)r1;
-        }
-#pragma unroll
-        for (int i = 0; i < NB; ++i) wrow[i] = Wp + (long)(n0 + ldrow + 64 * i) * wld + q * 8;
-    };
-    int ld_tile = blockIdx.x, ld_kt = 0, ld_stage = 0;           // next K-step to issue and the ring slot it goes to
-    bool ld_valid = ld_tile < total;
-    if (ld_valid) setup_loader(ld_tile);
-    auto tile_kq = [&](int kt) { return p.ktab_identity ? kt * 8 + q : ktab[kt * 8 + q]; };
-    auto issue_piece = [&](int kq, int i) {
-        char* st = dsmem + ld_stage * STAGE;
-        if (i < NA) {
-            const bool s1 = kq < 0;
-            const unsigned ko = (unsigned)kq & 0x7fffffffu;
-            const _Float16* g = (s1 ? lA1 : lA0) + ((unsigned long)((s1 ? rb1[i] : rb0[i]) + ko)) * 8;
-            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(g), LDS_PTR(st + (wv * 64 + 512 * i) * 16), 16, 0, 0);
-        } else {
-            const int j = i - NA;
-            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(wrow[j] + ld_kt * BK),
-                                             LDS_PTR(st + BM * BK * 2 + (wv * 64 + 512 * j) * 16), 16, 0, 0);
-        }
-    };
-    auto advance = [&]() {                                        // the step just issued is complete: move the load cursor
-        ld_stage = ld_stage + 1 == STAGES ? 0 : ld_stage + 1;
-        if (++ld_kt == nk) {
-            ld_kt = 0;
-            ld_tile += gridDim.x;
-            ld_valid = ld_tile < total;
-            if (ld_valid) setup_loader(ld_tile);
-        }
-    };
-    // prologue: STAGES - 1 steps in flight
-    int ahead = 0;                                                // issued steps not yet consumed
-#pragma unroll
-    for (int t = 0; t < STAGES - 1; ++t)
-        if (ld_valid) {
-            const int kq = tile_kq(ld_kt);
-#pragma unroll
-            for (int i = 0; i < NA + NB; ++i) issue_piece(kq, i);
-            advance();
-            ++ahead;
-        }
-
-    const int fr = lane & 15, fq = lane >> 4;
-    unsigned uoffA[2], uoffB[2];
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-        int c = (kk * 4 + fq) ^ (fr & 7);
-        uoffA[kk] = ((wm * TM + fr) * 8 + c) * 16;
-        uoffB[kk] = BM * BK * 2 + ((wn * TN + fr) * 8 + c) * 16;
-    }
-    const unsigned lds0 = (unsigned)(unsigned long)LDS_PTR(dsmem);
-    int cstage = 0;                                               // ring slot of the step being consumed
-
-    for (int t = blockIdx.x; t < total; t += gridDim.x) {
-        int m0, n0, z;
-        locate(t, m0, n0, z);
-        f32x4 acc[NI][MI];
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int kt = 0; kt < nk; ++kt) {
-            // the step being consumed landed for this wavefront; one younger step may stay in flight.  After an epilogue
-            // (kt == 0) its stores share the counter, so everything is drained once per tile.
-            if (ahead >= 2 && kt > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + NB) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            --ahead;
-            const bool more = ld_valid;
-            const int kq_next = more ? tile_kq(ld_kt) : 0;
-            const unsigned sbase = lds0 + cstage * STAGE;
-            cstage = cstage + 1 == STAGES ? 0 : cstage + 1;
-            f16x8 b[2][NI], a[2][2];
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) DS_READ128(b[0][ni], sbase + uoffB[0], ni * 2048);
-#pragma unroll
-            for (int e = 0; e < 2; ++e) DS_READ128(a[0][e], sbase + uoffA[0], e * 2048);
-#pragma unroll
-            for (int step = 0; step < MI; ++step) {
-                const int kk = step / (MI / 2), pr = step % (MI / 2), cur = step & 1, nxt = cur ^ 1;
-                if (step + 1 < MI) {
-                    const int kk2 = (step + 1) / (MI / 2), pr2 = (step + 1) % (MI / 2);
-#pragma unroll
-                    for (int e = 0; e < 2; ++e) DS_READ128(a[nxt][e], sbase + uoffA[kk2], (2 * pr2 + e) * 2048);
-                    if (pr2 == 0) {
-#pragma unroll
-                        for (int ni = 0; ni < NI; ++ni) DS_READ128(b[1][ni], sbase + uoffB[1], ni * 2048);
-                        LGKM_WAIT(2 + NI);
-                    } else {
-                        LGKM_WAIT(2);
-                    }
-                } else {
-                    LGKM_WAIT(0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int e = 0; e < 2; ++e)
-#pragma unroll
-                    for (int ni = 0; ni < NI; ++ni)
-                        acc[ni][2 * pr + e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[kk][ni], a[cur][e], acc[ni][2 * pr + e], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                if (more) {
-                    constexpr int PER = (NA + NB + MI - 1) / MI;
-#pragma unroll
-                    for (int i = step * PER; i < (step + 1) * PER && i < NA + NB; ++i) issue_piece(kq_next, i);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (more) { advance(); ++ahead; }
-        }
-        gemm_epilogue<MI, NI>(p, acc, m0 + wm * TM, n0 + wn * TN, fr, fq, z);
-    }
-}
-
-template <int BM, int BN, int WM, int WN>
-static int launch_persist(const advh_gemm_desc& d, hipStream_t s) {
-    const int tilesM = (d.M + BM - 1) / BM, tilesN = (d.N + BN - 1) / BN;
-    if (tilesN * BN > d.w_rows) return ADVH_EINVAL;
-    const long total = (long)tilesM * tilesN * (d.nz > 0 ? d.nz : 1);
-    const int grid = (int)(total < 256 ? total : 256);
-    hipLaunchKernelGGL((gemm_f16_persist_kernel<BM, BN, WM, WN>), dim3(grid), dim3(512), 3 * (BM + BN) * BK * 2, s, d, tilesM, tilesN);
-    return ADVH_LAUNCH_CHECK();
-}
-
-// ---------------------------------------------------------------------------------------------------
-// Ring variant: 512 threads, BM x BN x 32 K-tiles in a 4-stage LDS ring (32 KiB per stage at 256 x 256).
-// Three K-tiles are in flight at any time and the DMA stream is continuous: the wait at the top of an
-// iteration only retires the OLDEST tile (counted vmcnt), the two younger ones keep flying across the barrier.
-// 64-byte LDS rows (4 chunks): chunk c of row r lives at slot c ^ ((r >> 1) & 2), which is conflict-free for
-// the ds_read_b128 lane groups (checked by enumeration in tests/test_gemm_plan.py).
-constexpr int RK = 32, RSTAGES = 4, RING_KTAB_MAX = 2048;
-template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(512) void gemm_f16_ring_kernel(const advh_gemm_desc p) {
-    constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 16, NI = TN / 16;
-    constexpr int NA = BM / 128, NB = BN / 128;    // 16-byte chunks per thread per K-tile (512 threads, 4 chunks / row)
-    constexpr int STAGE = (BM + BN) * RK * 2;
-    constexpr int NLOAD = NA + NB;
-    static_assert(WM * WN == 8 && MI % 2 == 0, "8 wavefronts");
-    extern __shared__ __attribute__((aligned(16))) char dsmem[];
-    int* kt_lds = (int*)(dsmem + RSTAGES * STAGE);
-
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int wm = wv / WN, wn = wv % WN;
-    const int tilesN = (p.N + BN - 1) / BN;
-    const int nwg = gridDim.x;
-    int id = blockIdx.x;
-    {
-        const int q8 = nwg / 8, r8 = nwg % 8, xcd = id % 8;
-        id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + id / 8;
-    }
-    const int tile_n = id % tilesN, tile_m = id / tilesN;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int z = blockIdx.z;
-    const _Float16* A0 = (const _Float16*)p.A0 + p.a_sZ[0] * z * 8;
-    const _Float16* A1 = (const _Float16*)p.A1 + p.a_sZ[1] * z * 8;
-    const _Float16* Wp = (const _Float16*)p.W + p.w_sZ * z;
-    const int nk = p.Ktot / RK;
-    const bool ident = p.ktab_identity != 0;
-    if (!ident) {
-        for (int i = tid; i < nk * 4; i += 512) kt_lds[i] = p.ktab[i];
-        __syncthreads();
-    }
-
-    const int ldrow = tid >> 2;                          // + 128*i
-    const int q = (tid & 3) ^ ((ldrow >> 1) & 2);        // logical K-chunk this lane fetches (swizzled source)
-    long safe0 = (long)p.h0 * p.a_sH[0] + (long)p.w0 * p.a_sW[0] + p.a_c0[0];
-    long safe1 = (long)p.h0 * p.a_sH[1] + (long)p.w0 * p.a_sW[1] + p.a_c0[1];
-    unsigned rb0[NA], rb1[NA];
-    const RowDecomp rd(p.Wg, p.Hg);
-#pragma unroll
-    for (int i = 0; i < NA; ++i) {
-        unsigned m = m0 + ldrow + 128 * i;
-        unsigned w, h, b;
-        rd(m, b, h, w);
-        bool ok = m < (unsigned)p.M && (int)h >= p.h0 && (int)h < p.h1 && (int)w >= p.w0 && (int)w < p.w1;
-        long r0 = ok ? (long)b * p.a_sB[0] + (long)h * p.a_sH[0] + (long)w * p.a_sW[0] + p.a_c0[0] : safe0;
-        long r1 = ok ? (long)b * p.a_sB[1] + (long)h * p.a_sH[1] + (long)w * p.a_sW[1] + p.a_c0[1] : safe1;
-        rb0[i] = (unsigned)r0;
-        rb1[i] = (unsigned)r1;
-    }
-    const _Float16* wrow[NB];
-#pragma unroll
-    for (int i = 0; i < NB; ++i) wrow[i] = Wp + (long)(n0 + ldrow + 128 * i) * (p.w_ld ? p.w_ld : (long)p.Ktot) + q * 8;
-
-    const int fr = lane & 15, fq = lane >> 4;
-    const int phys = fq ^ ((fr >> 1) & 2);
-    const unsigned lds0 = (unsigned)(unsigned long)LDS_PTR(dsmem);
-    const unsigned uoffA = ((wm * TM + fr) * 4 + phys) * 16;
-    const unsigned uoffB = BM * RK * 2 + ((wn * TN + fr) * 4 + phys) * 16;
-
-    f32x4 acc[NI][MI];
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    auto issue = [&](int kt) {
-        const int kq = ident ? kt * 4 + q : kt_lds[kt * 4 + q];
-        char* st = dsmem + (kt % RSTAGES) * STAGE;
-        const bool s1 = kq < 0;
-        const unsigned ko = (unsigned)kq & 0x7fffffffu;
-        const _Float16* base = s1 ? A1 : A0;
-#pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            const _Float16* g = base + ((unsigned long)((s1 ? rb1[i] : rb0[i]) + ko)) * 8;
-            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(g), LDS_PTR(st + (wv * 64 + 512 * i) * 16), 16, 0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < NB; ++i)
-            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(wrow[i] + kt * RK), LDS_PTR(st + BM * RK * 2 + (wv * 64 + 512 * i) * 16), 16, 0, 0);
-    };
-#pragma unroll
-    for (int t = 0; t < RSTAGES - 1; ++t)
-        if (t < nk) issue(t);
-    for (int kt = 0; kt < nk; ++kt) {
-        // retire tile kt only: up to two younger tiles stay in flight across the barrier
-        if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NLOAD) : "memory");
-        else if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOAD) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                          // tile kt visible to all; stage (kt-1)%4 free
-        if (kt + RSTAGES - 1 < nk) issue(kt + RSTAGES - 1);
-        const unsigned sbase = lds0 + (kt % RSTAGES) * STAGE;
-        f16x8 b[NI], a[2][2];
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) DS_READ128(b[ni], sbase + uoffB, ni * 1024);
-#pragma unroll
-        for (int e = 0; e < 2; ++e) DS_READ128(a[0][e], sbase + uoffA, e * 1024);
-#pragma unroll
-        for (int pr = 0; pr < MI / 2; ++pr) {
-            const int cur = pr & 1, nxt = cur ^ 1;
-            if (pr + 1 < MI / 2) {
-#pragma unroll
-                for (int e = 0; e < 2; ++e) DS_READ128(a[nxt][e], sbase + uoffA, (2 * (pr + 1) + e) * 1024);
-                LGKM_WAIT(2);
-            } else {
-                LGKM_WAIT(0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int e = 0; e < 2; ++e)
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni)
-                    acc[ni][2 * pr + e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[ni], a[cur][e], acc[ni][2 * pr + e], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-    gemm_epilogue<MI, NI>(p, acc, m0 + wm * TM, n0 + wn * TN, fr, fq, z);
-}
-
-template <int BM, int BN, int WM, int WN>
-static int launch_ring(const advh_gemm_desc& d, hipStream_t s) {
-    const int tilesM = (d.M + BM - 1) / BM, tilesN = (d.N + BN - 1) / BN;
-    if (tilesN * BN > d.w_rows || d.Ktot / 8 > RING_KTAB_MAX) return ADVH_EINVAL;
-    dim3 grid(tilesM * tilesN, 1, d.nz > 0 ? d.nz : 1);
-    hipLaunchKernelGGL((gemm_f16_ring_kernel<BM, BN, WM, WN>), grid, dim3(512), RSTAGES * (BM + BN) * RK * 2 + RING_KTAB_MAX * 4, s, d);
-    return ADVH_LAUNCH_CHECK();
-}
-
 }  // namespace advh
 
 using namespace advh;
 
 int advh_init_rest() {
     const int maxlds = 160 * 1024;
-    if (hipFuncSetAttribute((const void*)gemm_f16_pipe_kernel<256, 256, 2, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, maxlds) != hipSuccess) return ADVH_ELAUNCH;
-    if (hipFuncSetAttribute((const void*)gemm_f16_pipe_kernel<256, 128, 4, 2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, maxlds) != hipSuccess) return ADVH_ELAUNCH;
-    if (hipFuncSetAttribute((const void*)gemm_f16_ring_kernel<256, 256, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, maxlds) != hipSuccess) return ADVH_ELAUNCH;
-    if (hipFuncSetAttribute((const void*)gemm_f16_pipe_kernel<256, 256, 2, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, maxlds) != hipSuccess) return ADVH_ELAUNCH;
-    if (hipFuncSetAttribute((const void*)gemm_f16_persist_kernel<256, 128, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, maxlds) != hipSuccess) return ADVH_ELAUNCH;
 #define X3_ATTR(BM_, BN_, WM_, WN_)                                                                                                        \
     if (hipFuncSetAttribute((const void*)gemm_x3_kernel<BM_, BN_, WM_, WN_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, maxlds) != hipSuccess || \
         hipFuncSetAttribute((const void*)gemm_x3_kernel<BM_, BN_, WM_, WN_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, maxlds) != hipSuccess)   \
@@ -1600,9 +1112,6 @@ extern "C" int advh_gemm_f16(const advh_gemm_desc* d, int tile, advh_stream_t st
     if (d->plain && !d->ktab_identity) return ADVH_EINVAL;
     if (d->plain_out && (d->n_div < d->N || d->ph_r > 0 || d->n_sub > 1 || d->h0 != 0 || d->w0 != 0 || d->h1 != d->Hg || d->w1 != d->Wg))
         return ADVH_EINVAL;
-    if ((d->nz_lo > 1 || d->z_inner) && (tile == ADVH_TILE_256x256 || tile == ADVH_TILE_256x256_RING || tile == ADVH_TILE_256x128 ||
-                                          tile == ADVH_TILE_256x128_PERSIST || tile == ADVH_TILE_256x256_W4))
-        return ADVH_EUNSUPPORTED;                        // the two-level batch lives in gemm_f16_kernel only
     if (d->split) {                                      // fp32-class instance: split-format operands, 3 MFMAs per fragment pair
         switch (tile) {
             case ADVH_TILE_128x128: return launch_x3<128, 128, 2, 2>(*d, s);
@@ -1615,16 +1124,9 @@ extern "C" int advh_gemm_f16(const advh_gemm_desc* d, int tile, advh_stream_t st
         case ADVH_TILE_128x128: return launch<128, 128, 2, 2, 4>(*d, s);   // 4 wavefronts per SIMD: <= 128 VGPRs, checked spill-free
         case ADVH_TILE_256x64: return launch<256, 64, 4, 1, 3>(*d, s);
         case ADVH_TILE_256x32: return launch<256, 32, 4, 1, 3>(*d, s);
-        case ADVH_TILE_256x128_W4: return launch<256, 128, 2, 2, 2>(*d, s);
-        case ADVH_TILE_128x256_W4: return launch<128, 256, 2, 2, 2>(*d, s);
         case ADVH_TILE_256x128_W8: return launch<256, 128, 4, 2, 3>(*d, s);
         case ADVH_TILE_128x256_W8: return launch<128, 256, 2, 4, 3>(*d, s);
-        case ADVH_TILE_256x256: return launch_pipe<256, 256, 2, 4, 2>(*d, s);
-        case ADVH_TILE_256x256_RING: return launch_ring<256, 256, 2, 4>(*d, s);
-        case ADVH_TILE_256x128: return launch_pipe<256, 128, 4, 2, 3>(*d, s);
-        case ADVH_TILE_256x128_PERSIST: return launch_persist<256, 128, 4, 2>(*d, s);
-        case ADVH_TILE_256x256_W4: return launch_pipe<256, 256, 2, 2, 2>(*d, s);
-        default: return ADVH_EINVAL;
+        default: return ADVH_EINVAL;       // the ring / pipelined / persistent variants of rounds 1-2 measured slower on every pipeline shape and were removed
     }
 }
 
