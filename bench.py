@@ -226,6 +226,55 @@ def run_explain(ctx, precision, steps, warmup, vocoder=False, cfg=None):
     return res
 
 
+HBM_PEAK_GBS = 8000.0                 # MI355X HBM3E (MI355X_MICROARCH.md)
+
+
+def stft_roofline(dev, B=BATCH, reps=20):
+    """HBM roofline of the two signal kernels north_star names first (csrc/stft.hip), as the explanation step runs them:
+    framed rFFT `advh_stft_forward` (X + |X|, no phase) and the fused masked inverse `advh_istft_masked_c64` (mask application
+    + irFFT + overlap-add, mask-in AND mask-out).  `achieved` = bytes each launch actually moves (every operand and result once)
+    / average launch time from HIP events on the launch stream; `algorithmic` = SURVEY.md §8(d)'s per-clip accounting
+    (1.89 MB forward with the phase output, 2 x 1.47 MB inverse with magnitude + phase inputs)."""
+    import torch
+    from addvisor_hip import _lib, ops, synthetic as syn
+    L, hop, win = AUDIO_LENGTH * 16000, 322, 644
+    w = syn.make_clips(B, L).to(dev)
+    spec, mag, _ = ops.stft_forward(w, L, hop, win, want_complex=True, want_phase=False)
+    T, Fm, Tm = mag.shape[2], 512, (mag.shape[2] // 4) * 4
+    mask = torch.rand(B, Fm, Tm, device=dev)
+    o_in, o_out = torch.empty(B, L, device=dev), torch.empty(B, L, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    xr = torch.view_as_real(spec)
+
+    def inverse():
+        _lib.check(_lib.lib().advh_istft_masked_c64(xr.data_ptr(), mask.data_ptr(), Fm, Tm, 2, o_in.data_ptr(), o_out.data_ptr(), L, B, T, L,
+                                                    hop, win, None, st), "advh_istft_masked_c64")
+
+    def timed(fn):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) / reps * 1e-3
+
+    t_f = timed(lambda: ops.stft_forward(w, L, hop, win, want_complex=True, want_phase=False))
+    t_i = timed(inverse)
+    nb = 513 * T
+    moved_f = B * (L * 4 + nb * 8 + nb * 4)                          # wave in; X (c64) + |X| out
+    moved_i = B * (nb * 8 + Fm * Tm * 4 + 2 * L * 4)                 # X (c64) + mask in; two waveforms out
+    alg_f, alg_i = B * 1.89e6, B * 2 * 1.47e6
+    rec = lambda kern, t, moved, alg: {"kernel": kern, "bound": "hbm", "us_per_launch": round(t * 1e6, 1), "bytes_moved": int(moved),
+                                       "achieved": round(moved / t / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                       "frac": round(moved / t / 1e9 / HBM_PEAK_GBS, 4),
+                                       "algorithmic_GBs_survey_8d": round(alg / t / 1e9, 1)}
+    return {"workload": f"{B} clips x 4 s, as inside the explanation step", "stft_forward": rec("stft_fwd_kernel (X + |X|)", t_f, moved_f, alg_f),
+            "istft_masked": rec("istft_kernel (complex source, mask-in + mask-out, log1p domain)", t_i, moved_i, alg_i)}
+
+
 def gemm_roofline(G, precision, tuned=False, committed=False):
     """`committed`: attach the committed PMC traffic figure (profiles/*gemm_traffic.json) -- only meaningful for the default explain
     workload those passes ran; every other workload reports traffic null unless it measures its own."""
@@ -318,6 +367,8 @@ def explain_line(ctx):
         "roofline": head["roofline"],
         "cpu_baseline": None,
     }
+    if rank == 0:
+        line["roofline_hbm"] = stft_roofline(ctx["dev"], B)
     extras = world == 1 and not args.no_extras and not args.tune
     if rank == 0 and world == 1 and not args.no_traffic and not args.tune and head["roofline"]["launches"]:
         kern = head["roofline"]["kernel"]
