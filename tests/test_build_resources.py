@@ -1,0 +1,42 @@
+"""CPU-only: the matrix-core kernels of the hot path must compile WITHOUT scratch (register spills).  A spill in
+`gemm_x3_kernel` is a 2.5x slowdown of the whole fp32-class mode that no parity test sees (it happened in round 3 when a branch
+was added to `split_f32`): hipcc's kernel-resource remarks are parsed for every GEMM instantiation."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "xai-audio-deepfakes_amd", "csrc")
+
+
+def resources(src):
+    r = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-function",
+                        f"-I{os.path.join(ROOT, 'include')}", f"-I{CSRC}", "-Rpass-analysis=kernel-resource-usage", "-c",
+                        os.path.join(CSRC, src), "-o", os.devnull], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out, name = {}, None
+    for line in r.stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+            out[name] = {}
+        for key, pat in (("vgprs", r"\bVGPRs: (\d+)"), ("scratch", r"ScratchSize \[bytes/lane\]: (\d+)"), ("occupancy", r"Occupancy \[waves/SIMD\]: (\d+)")):
+            m = re.search(pat, line)
+            if m and name:
+                out[name][key] = int(m.group(1))
+    return out
+
+
+def test_gemm_kernels_do_not_spill():
+    res = resources("gemm.hip")
+    x3 = {k: v for k, v in res.items() if "gemm_x3_kernel" in k}
+    f16 = {k: v for k, v in res.items() if "gemm_f16_kernel" in k}
+    assert len(x3) == 6 and len(f16) >= 4, sorted(res)
+    for k, v in {**x3, **f16}.items():
+        assert v["scratch"] == 0, (k, v)
+    for k, v in x3.items():
+        assert v["occupancy"] >= 2, (k, v)                     # two co-resident workgroups hide each other's DMA
+    main = [v for k, v in f16.items() if "ILi128ELi128ELi2ELi2ELi4E" in k]
+    assert main and all(v["occupancy"] >= 4 for v in main), main      # 4 workgroups per CU on the fp16 128x128 tile

@@ -38,23 +38,20 @@ __device__ __forceinline__ float gelu_fast(float x) { return 0.5f * x * (1.f + f
 // A value beyond that SATURATES (hi = +-65504, lo = the clamped remainder: x up to +-65535.98 is still exact) instead of
 // turning into inf / NaN downstream, and raises the library's sticky range flag -- one host-mapped word the device writes
 // and the host reads without synchronising (advh_split_overflow; the Python binding turns it into an error at its next call).
-// NaN inputs stay NaN and raise the flag too.
+// NaN inputs raise the flag too (their planes are unspecified finite values).
 constexpr float SPLIT_LO_SCALE = 2048.f, SPLIT_LO_INV = 1.f / 2048.f, SPLIT_MAX = 65504.f;
-static __device__ int* g_split_flag = nullptr;       // this translation unit's copy of the flag pointer (set by advh_init)
+static __constant__ int* g_split_flag = nullptr;     // this translation unit's copy of the flag pointer (set by advh_init); constant
+                                                     // address space: the load is scalar and never ordered against the epilogue's stores
 __device__ __forceinline__ void split_f32(float x, _Float16& hi, _Float16& lo) {
-    if (!(fabsf(x) <= SPLIT_MAX)) {                  // out of range, or NaN (rare path)
-        if (g_split_flag) *(volatile int*)g_split_flag = 1;
-        if (x == x) {
-            const float h = copysignf(SPLIT_MAX, x);
-            hi = (_Float16)h;
-            lo = (_Float16)fminf(fmaxf((x - h) * SPLIT_LO_SCALE, -SPLIT_MAX), SPLIT_MAX);
-            return;
-        }
-    }
-    _Float16 h = (_Float16)x;
+    // branch-free value path (the in-range result is bit-identical to the unclamped form): two v_med3 per value
+    _Float16 h = (_Float16)__builtin_amdgcn_fmed3f(x, -SPLIT_MAX, SPLIT_MAX);
     if (fabsf(x) < 6.103515625e-05f) h = (_Float16)0.f;
     hi = h;
-    lo = (_Float16)((x - (float)h) * SPLIT_LO_SCALE);
+    lo = (_Float16)__builtin_amdgcn_fmed3f((x - (float)h) * SPLIT_LO_SCALE, -SPLIT_MAX, SPLIT_MAX);
+    if (!(fabsf(x) <= SPLIT_MAX)) {                  // out of range, or NaN: one exec-masked store on a path that is never taken in range
+        int* f = g_split_flag;
+        if (f) *(volatile int*)f = 1;
+    }
 }
 // defines this translation unit's setter of g_split_flag (called by advh_init on every device it initialises)
 #define ADVH_SPLIT_FLAG_SETTER(name)                                                                                       \
