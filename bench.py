@@ -164,8 +164,8 @@ def main():
 # ------------------------------------------------------------------------------------------ the explanation step
 def run_explain(ctx, precision, steps, warmup, vocoder=False, cfg=None):
     """Time `steps` explanation steps in one precision; returns the numbers of that run.  `vocoder`: the north-star variant
-    in which both resyntheses are re-rendered by the HiFi-GAN V1 vocoder (mel front end + generator, fp16 operands) before
-    the classifier re-forward."""
+    in which both resyntheses are re-rendered by the HiFi-GAN V1 vocoder (mel front end + generator, same precision as the rest
+    of the path) before the classifier re-forward."""
     import torch
     from addvisor_hip import gemm as G, pipeline as P, synthetic as syn
     args, dev, rank, world, dist = ctx["args"], ctx["dev"], ctx["rank"], ctx["world"], ctx["dist"]
@@ -177,7 +177,7 @@ def run_explain(ctx, precision, steps, warmup, vocoder=False, cfg=None):
     if vocoder:
         from addvisor_hip.hifigan import HipHifigan
         hcfg = syn.HifiganConfig()
-        voc = HipHifigan(hcfg, syn.hifigan_weights(hcfg), dev)
+        voc = HipHifigan(hcfg, syn.hifigan_weights(hcfg), dev, precision=precision)      # the vocoder runs at the path's precision
     pipe = P.ExplainPipeline(cfg, emb_sd, coef, icpt, unet_sd, dev, audio_length=AUDIO_LENGTH, streams=args.streams, precision=precision,
                              vocoder=voc)
     B, L = args.batch, AUDIO_LENGTH * 16000
@@ -385,9 +385,9 @@ def explain_line(ctx):
                        "pipeline_tflops": round(o["flops_step"] * args.steps / o["elapsed"] / 1e12, 1), "roofline": o["roofline"]}
         v = run_explain(ctx, args.precision, 3, 1, vocoder=True)
         line["explain_vocoder"] = {"workload": "the same step with both resyntheses re-rendered by the HiFi-GAN V1 vocoder (mel front end + generator, "
-                                               "128 clips x 251 frames per step, fp16 operands) before the classifier re-forward",
+                                               "128 clips x 251 frames per step, at the path's precision) before the classifier re-forward",
                                    "value": round(v["value"], 2), "unit": "explanations/s", "ms_per_step": round(1e3 * v["elapsed"] / v["steps"], 3),
-                                   "steps": v["steps"], "dtype": f"{args.precision} (embedder, U-Net) + f16 (vocoder)",
+                                   "steps": v["steps"], "dtype": args.precision,
                                    "lmac": {k: round(x, 6) for k, x in v["metrics"].items()}}
         line["xlsr2b"] = bench_xlsr2b(ctx, args.precision)
         line["dataset"] = bench_dataset(ctx, args.precision)
