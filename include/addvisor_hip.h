@@ -404,6 +404,22 @@ int advh_w2v2_frontend_bwd_group_split(const float* wave, int64_t wave_stride, i
                                        const float* gamma, const float* stats_ws, const float* norm_ws, const float* mr_ws,
                                        const void* dy0, int64_t dy_lo, float* part_ws, float* sums_ws, void* dz0, int64_t dz_lo,
                                        int T0, int P0, int C0, advh_stream_t stream);
+/* fp32-class form of advh_resblock_pair_f16 for the 32-channel stage (csrc/resblock_pair_x3.hip): X / out_h are split-format maps
+ * [2][M][32] (lo plane x_lo / o_lo elements behind), W1 / W2 [2][k][C_out][C_in] fp16 planes (w_lo elements apart), three MFMAs
+ * per product in the K order of the x3 implicit GEMM.  C = 32 only; advh_resblock_pair_x3_lds_bytes < 0: unsupported.       */
+typedef struct advh_resblock_x3_desc {
+    const void* X;
+    const void* W1;
+    const float* b1;
+    const void* W2;
+    const float* b2;
+    void* out_h;
+    int M, Wg, w0, w1, k, dil;
+    float slope;
+    int64_t x_lo, o_lo, w_lo;
+} advh_resblock_x3_desc;
+int advh_resblock_pair_x3_lds_bytes(int C, int k, int dil);
+int advh_resblock_pair_x3(const advh_resblock_x3_desc* d, int C, advh_stream_t stream);
 /* HiFi-GAN generator pieces on split-format maps [2][B][T+2*halo][C] (the Conv1d / ConvTranspose1d layers are advh_gemm_f16
  * launches with desc.split = 1; advh_halo_fill_f16 serves both planes when called with 2*B maps).  `pad` = inference padding. */
 int advh_hifigan_pack_mel_split(const float* mel, void* out, int64_t out_lo, int B, int C, int T, int pad, int halo,

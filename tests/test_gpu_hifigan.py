@@ -105,3 +105,25 @@ def test_v1_generator_f32_mode(gpu_device, padding_mode, inference_padding):
     print(f"hifigan f32 mode ({padding_mode}, pad {inference_padding}): max err {err.max():.3e} mean {err.mean():.3e}")
     assert err.max().item() <= 1e-4 and err.mean().item() <= 1e-5
     assert torch.equal(net.decode_batch(mel[:1].to(gpu_device))[0], wav[0])     # batch invariance
+
+
+def test_v1_f32_fused_resblock_matches_unfused(gpu_device):
+    """csrc/resblock_pair_x3.hip (the 32-channel stage's ResBlock steps as ONE fused split-format kernel each: the north-star's "MRF
+    dilated-ResBlock Conv1d as LDS line-tile kernels" in the fp32-class mode) against the layer-by-layer x3 implicit-GEMM path: same
+    three-MFMA arithmetic in the same K order, so the waveforms agree to the last bits of the split representation (stated 2e-6
+    on a waveform in [-1, 1]); clip boundaries inside a tile, a ragged last tile and batch invariance included."""
+    cfg = syn.HifiganConfig()
+    sd = syn.hifigan_weights(cfg)
+    r = np.random.Generator(np.random.PCG64(8))
+    mel = torch.from_numpy(r.normal(-4.0, 2.0, size=(3, cfg.in_channels, 37)).astype(np.float32))
+    fused = HipHifigan(cfg, sd, gpu_device, precision="f32")
+    plain = HipHifigan(cfg, sd, gpu_device, precision="f32", fuse=False)
+    kinds = [type(s[1]).__name__ for s in fused._workspace(3, 37)["steps"] if s[0] == "gemm"]
+    assert kinds.count("ResblockPairX3Plan") == 9 and not any("X3" in type(s[1]).__name__ for s in plain._workspace(3, 37)["steps"] if s[0] == "gemm")
+    a, b = fused.decode_batch(mel.to(gpu_device)), plain.decode_batch(mel.to(gpu_device))
+    err = (a - b).abs().max().item()
+    ref = hifigan_ref.generator(mel, sd, cfg)
+    print(f"f32 fused vs unfused ResBlock steps: {err:.3e}; fused vs oracle {(a.cpu() - ref).abs().max():.3e}, unfused vs oracle {(b.cpu() - ref).abs().max():.3e}")
+    assert err <= 2e-6
+    assert (a.cpu() - ref).abs().max().item() <= 1e-4
+    assert torch.equal(fused.decode_batch(mel[1:2].to(gpu_device))[0], a[1])          # batch invariance

@@ -11,7 +11,7 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 T, steps = 251, 5
 dev = torch.device("cuda:0")
 cfg = syn.HifiganConfig()
-net = HipHifigan(cfg, syn.hifigan_weights(cfg), dev)
+net = HipHifigan(cfg, syn.hifigan_weights(cfg), dev, precision=os.environ.get("HIFIGAN_PRECISION", "f32"))
 mel = torch.randn(B, 80, T, device=dev) * 2 - 4
 net.decode_batch(mel); torch.cuda.synchronize()
 G.PROFILE.reset(True)

@@ -989,6 +989,63 @@ class ResblockPairPlan:
         _lib.check(_lib.lib().advh_resblock_pair_f16(C.byref(d), self.Cn, stream), "advh_resblock_pair_f16")
 
 
+class ResblockX3Desc(C.Structure):
+    """Mirror of ``advh_resblock_x3_desc`` (include/addvisor_hip.h)."""
+    _fields_ = [("X", C.c_void_p), ("W1", C.c_void_p), ("b1", C.c_void_p), ("W2", C.c_void_p), ("b2", C.c_void_p),
+                ("out_h", C.c_void_p), ("M", C.c_int), ("Wg", C.c_int), ("w0", C.c_int), ("w1", C.c_int), ("k", C.c_int),
+                ("dil", C.c_int), ("slope", C.c_float), ("x_lo", C.c_int64), ("o_lo", C.c_int64), ("w_lo", C.c_int64)]
+
+
+def resblock_pair_x3_lds_bytes(Cn: int, k: int, dil: int) -> int:
+    """Host copy of ``advh_resblock_pair_x3_lds_bytes``: two weight tensors x two planes + one or two split line buffers; -1 = no."""
+    if Cn != 32 or k < 1 or k % 2 == 0 or k > 15 or dil < 1:
+        return -1
+    rows = max(256 + (k - 1) * dil, 272)
+    buf = 2 * ((rows * 4 + 63) // 64 * 64) * 16
+    one = 4 * k * 32 * 32 * 2 + buf
+    lds = one if (one <= 80 * 1024 or one + buf > TAPS_MAX_LDS) else one + buf
+    return lds if lds <= TAPS_MAX_LDS else -1
+
+
+def resblock_pair_x3_supported(src: Map1D, dst: Map1D, w1: torch.Tensor, w2: torch.Tensor, dilation: int) -> bool:
+    Cn, k = w1.shape[0], w1.shape[2]
+    return (src.split and dst.split and Cn == 32 and tuple(w1.shape) == (Cn, Cn, k) and tuple(w2.shape) == (Cn, Cn, k) and k % 2 == 1
+            and src.C == Cn and dst.C == Cn and (src.B, src.T, src.halo) == (dst.B, dst.T, dst.halo)
+            and src.halo >= (k - 1) * dilation // 2 and resblock_pair_x3_lds_bytes(Cn, k, dilation) > 0)
+
+
+class ResblockPairX3Plan:
+    """One launch of ``advh_resblock_pair_x3``: ``dst = src + conv2(lrelu(conv1(lrelu(src))))`` on split-format maps (the fp32-class
+    form of ``ResblockPairPlan``; HiFi-GAN ResBlock1 step of the 32-channel stage)."""
+
+    def __init__(self, src: Map1D, dst: Map1D, w1, b1, w2, b2, *, dilation: int, slope: float, device=None):
+        assert resblock_pair_x3_supported(src, dst, w1, w2, dilation)
+        Cn, k = w1.shape[0], w1.shape[2]
+        self.Cn = Cn
+        pack = lambda w: split_planes(w.permute(2, 0, 1)).contiguous()          # [2][k][C_out][C_in]
+        self.w1, self.w2 = pack(w1), pack(w2)
+        self.b1, self.b2 = b1.to(torch.float32).contiguous(), b2.to(torch.float32).contiguous()
+        if device is not None:
+            self.w1, self.w2, self.b1, self.b2 = (t.to(device) for t in (self.w1, self.w2, self.b1, self.b2))
+        d = ResblockX3Desc()
+        d.M, d.Wg, d.w0, d.w1, d.k, d.dil, d.slope = dst.B * dst.P, dst.P, dst.halo, dst.halo + dst.T, k, dilation, slope
+        d.w_lo = k * Cn * Cn
+        self.desc = d
+        self.flops = 2 * 2.0 * dst.B * dst.T * Cn * Cn * k
+        self.tile = None
+
+    def run(self, A0: torch.Tensor, A1=None, *, out_h: torch.Tensor, stream: Optional[int] = None, **_):
+        d = self.desc
+        for t in (A0, out_h):
+            assert t.dtype == torch.float16 and t.is_cuda and t.shape[0] == 2 and t[0].is_contiguous() and t[0].numel() == d.M * self.Cn
+        assert A0.data_ptr() != out_h.data_ptr()
+        d.X, d.out_h, d.x_lo, d.o_lo = A0.data_ptr(), out_h.data_ptr(), A0.stride(0), out_h.stride(0)
+        d.W1, d.W2, d.b1, d.b2 = self.w1.data_ptr(), self.w2.data_ptr(), self.b1.data_ptr(), self.b2.data_ptr()
+        if stream is None:
+            stream = torch.cuda.current_stream().cuda_stream
+        _lib.check(_lib.lib().advh_resblock_pair_x3(C.byref(d), self.Cn, stream), "advh_resblock_pair_x3")
+
+
 def taps_supported(src: Map1D, dst: Map1D, weight: torch.Tensor, dilation: int) -> bool:
     Cout, Cin, k = weight.shape
     return (Cout == Cin and Cin in (32, 64) and src.C == Cin and dst.C == Cout and src.halo == dst.halo and k <= 16

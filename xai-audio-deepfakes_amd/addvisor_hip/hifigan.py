@@ -42,8 +42,11 @@ class HipHifigan:
         if precision not in ("f16", "f32"):
             raise ValueError("precision must be 'f16' or 'f32'")
         self.precision, self.split = precision, precision == "f32"
+        # fp32-class mode: the 32-channel ResBlock steps have a fused split-format kernel (csrc/resblock_pair_x3.hip); the other
+        # line-tile kernels are fp16-only, those layers run the x3 implicit GEMM
+        self.fuse_x3 = self.split and fuse and padding_mode == "zeros"
         if self.split:
-            line_tile = fuse = False                       # the line-tile kernels are fp16-only
+            line_tile = fuse = False
         if padding_mode not in ("zeros", "reflect"):
             raise ValueError("padding_mode must be 'zeros' or 'reflect'")
         if inference_padding < 0:
@@ -103,6 +106,10 @@ class HipHifigan:
             # line buffer: no pre-activated copies are stored or read there
             in_lds = self.line_tile and co in (32, 64) and all(
                 G.taps_tile(co, k, (k - 1) * max(cfg.resblock_dilations)) > 0 for k in cfg.resblock_kernel_sizes)
+            # fp32-class mode: a stage whose EVERY ResBlock step has the fused split-format kernel needs no pre-activated copies either
+            x3_stage = self.fuse_x3 and all(G.resblock_pair_x3_lds_bytes(co, k, dd) > 0 for k in cfg.resblock_kernel_sizes
+                                            for dd in cfg.resblock_dilations) and HALO >= (max(cfg.resblock_kernel_sizes) - 1) * max(cfg.resblock_dilations) // 2
+            in_lds = in_lds or x3_stage
             x = M(t2, co)
             lx = None if in_lds else M(t2, co)
             steps.append(("gemm", G.plan_convT1d(cur, x, sd[f"ups.{i}.weight"], sd[f"ups.{i}.bias"], stride=r,
@@ -120,6 +127,13 @@ class HipHifigan:
                     last = d == nd - 1
                     ox = outs[j] if last else (pa if d % 2 == 0 else pb)
                     w1, w2 = sd[p + f"convs1.{d}.weight"], sd[p + f"convs2.{d}.weight"]
+                    if x3_stage:
+                        assert G.resblock_pair_x3_supported(cx, ox, w1, w2, cfg.resblock_dilations[d])
+                        steps.append(("gemm", G.ResblockPairX3Plan(cx, ox, w1, sd[p + f"convs1.{d}.bias"], w2, sd[p + f"convs2.{d}.bias"],
+                                                                  dilation=cfg.resblock_dilations[d], slope=cfg.leaky_slope, device=dev),
+                                      cx, None, ox, None))
+                        cx, clx = ox, None
+                        continue
                     if in_lds and self.fuse and G.resblock_pair_supported(cx, ox, w1, w2, cfg.resblock_dilations[d]):
                         # both convolutions of the step in one kernel, the intermediate map stays in LDS
                         steps.append(("gemm", G.ResblockPairPlan(cx, ox, w1, sd[p + f"convs1.{d}.bias"], w2, sd[p + f"convs2.{d}.bias"],

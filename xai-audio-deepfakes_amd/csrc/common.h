@@ -17,6 +17,7 @@ int advh_split_flag_hifigan(int* flag);
 int advh_split_flag_rowops(int* flag);
 int advh_split_flag_unet_misc(int* flag);
 int advh_split_flag_unet_train(int* flag);
+int advh_split_flag_resblock_pair_x3(int* flag);
 
 // Raise a kernel's dynamic-LDS limit to `bytes` once per (kernel, DEVICE): the attribute belongs to the device's copy of
 // the code object, and one process may drive several GPUs (a per-process "done" flag left the second device at 64 KiB).
