@@ -970,72 +970,6 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_x3_kernel(const advh_gem
         if (blockIdx.x == gridDim.x / 2 && tid == 0 && kt == 6) g_kstep[0] = __builtin_amdgcn_s_memtime();
         if (blockIdx.x == gridDim.x / 2 && tid == 0 && kt == 7) g_kstep[5] = __builtin_amdgcn_s_memtime();
 #endif
-#ifdef ADVH_X3_HI_FIRST
-        // EXPERIMENT (round 3, tools/experiments/x3_hi_first.sh): the hi planes of a K-step are issued first and the 32 hi x hi MFMAs
-        // start as soon as they have landed, while the lo planes are still in flight; the 64 cross-term MFMAs follow after a second
-        // wait + barrier.  Per-accumulator order is unchanged (bit-identical results).
-        if constexpr (PLAIN) {
-#pragma unroll
-            for (int i = 0; i < NA; ++i) __builtin_amdgcn_global_load_lds(GLOBAL_PTR(ap[i] + kt * BK), LDS_PTR(ldsA + (wv * 64 + NT * i) * 16), 16, 0, 0);
-#pragma unroll
-            for (int i = 0; i < NB; ++i) __builtin_amdgcn_global_load_lds(GLOBAL_PTR(wp0 + i * wstep + kt * BK), LDS_PTR(ldsB + (wv * 64 + NT * i) * 16), 16, 0, 0);
-#pragma unroll
-            for (int i = 0; i < NA; ++i) __builtin_amdgcn_global_load_lds(GLOBAL_PTR(ap[i] + alo0 + kt * BK), LDS_PTR(ldsA + PA + (wv * 64 + NT * i) * 16), 16, 0, 0);
-#pragma unroll
-            for (int i = 0; i < NB; ++i) __builtin_amdgcn_global_load_lds(GLOBAL_PTR(wp0 + wlo + i * wstep + kt * BK), LDS_PTR(ldsB + PB + (wv * 64 + NT * i) * 16), 16, 0, 0);
-        } else {
-            const bool s1 = kq < 0;
-            const unsigned ko = (unsigned)kq & 0x7fffffffu;
-            const _Float16* base = s1 ? A1 : A0;
-            const long alo = s1 ? alo1 : alo0;
-#pragma unroll
-            for (int i = 0; i < NA; ++i) __builtin_amdgcn_global_load_lds(GLOBAL_PTR(base + ((unsigned long)((s1 ? rb1[i] : rb0[i]) + ko)) * 8), LDS_PTR(ldsA + (wv * 64 + NT * i) * 16), 16, 0, 0);
-#pragma unroll
-            for (int i = 0; i < NB; ++i) __builtin_amdgcn_global_load_lds(GLOBAL_PTR(wrow[i] + kt * BK), LDS_PTR(ldsB + (wv * 64 + NT * i) * 16), 16, 0, 0);
-#pragma unroll
-            for (int i = 0; i < NA; ++i) __builtin_amdgcn_global_load_lds(GLOBAL_PTR(base + ((unsigned long)((s1 ? rb1[i] : rb0[i]) + ko)) * 8 + alo), LDS_PTR(ldsA + PA + (wv * 64 + NT * i) * 16), 16, 0, 0);
-#pragma unroll
-            for (int i = 0; i < NB; ++i) __builtin_amdgcn_global_load_lds(GLOBAL_PTR(wrow[i] + wlo + kt * BK), LDS_PTR(ldsB + PB + (wv * 64 + NT * i) * 16), 16, 0, 0);
-            if (kt + 1 < nk) kq = p.ktab[(kt + 1) * 8 + q];
-        }
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + NB) : "memory");          // this wavefront's hi-plane pieces landed
-        __syncthreads();
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            f16x8 bh[NI];
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) bh[ni] = *(const f16x8*)(ldsB + offB[kk] + ni * 16 * 128);
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi) {
-                const f16x8 ah = *(const f16x8*)(ldsA + offA[kk] + mi * 16 * 128);
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni) acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[ni], ah, acc[ni][mi], 0, 0, 0);
-            }
-        }
-        __builtin_amdgcn_s_setprio(0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            f16x8 bh[NI], bl[NI];
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) {
-                bh[ni] = *(const f16x8*)(ldsB + offB[kk] + ni * 16 * 128);
-                bl[ni] = *(const f16x8*)(ldsB + PB + offB[kk] + ni * 16 * 128);
-            }
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi) {
-                const f16x8 ah = *(const f16x8*)(ldsA + offA[kk] + mi * 16 * 128);
-                const f16x8 al = *(const f16x8*)(ldsA + PA + offA[kk] + mi * 16 * 128);
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni) accx[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[ni], al, accx[ni][mi], 0, 0, 0);
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni) accx[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[ni], ah, accx[ni][mi], 0, 0, 0);
-            }
-        }
-#else
         if constexpr (PLAIN) {
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
@@ -1098,7 +1032,6 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_x3_kernel(const advh_gem
                 for (int ni = 0; ni < NI; ++ni) accx[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[ni], ah, accx[ni][mi], 0, 0, 0);
             }
         }
-#endif
         __builtin_amdgcn_s_setprio(0);
 #ifdef ADVH_STAMPS
         if (stamp_here) g_kstep[4] = __builtin_amdgcn_s_memtime();     // MFMAs issued
