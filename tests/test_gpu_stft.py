@@ -140,3 +140,19 @@ def test_stft_full_batch_property(gpu_device):
     back = ops.istft_complex(X, L)
     assert (back - w).abs().max().item() < TOL_WAVE
     assert torch.allclose(mag, X.abs(), rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("hop,win", [(322, 644), (321, 642), (256, 1024), (160, 400)])
+def test_istft_overlap_add_without_atomics_roundtrip(gpu_device, hop, win):
+    """Round 3: the inverse writes every frame's windowed samples into the frame's own LDS rows and sums the R overlapping frames at
+    emit time (round 2 used LDS float atomics: 114 LDS cycles each).  STFT -> ISTFT is the identity for any hop / window length the
+    kernel accepts: the reference's 644 / 322, a window with an ODD left offset (win % 4 == 2: scalar stores), Hann-size 1024 / 256
+    (four overlapping frames, samples spill into the second row) and a short window."""
+    L = 16000
+    w = syn.make_clips(3, L, seed=55)
+    X, _, _ = ops.stft_forward(w.to(gpu_device), L, hop, win)
+    back = ops.istft_complex(X, L, hop, win)
+    assert back.shape == (3, L)
+    err = (back.cpu() - w).abs().max().item()
+    print(f"roundtrip hop {hop} win {win}: {err:.2e}")
+    assert err < TOL_WAVE

@@ -2,7 +2,8 @@
 each with the epilogue the embedder gives it (h: fp16-side output; g: GELU; r: fp32 residual stream), after a 1 s warm-up
 (the clock settles only after ~1 s of load: a cold measurement reads 20-25 % low)."""
 import sys, time, torch
-sys.path.insert(0, "xai-audio-deepfakes_amd")
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "xai-audio-deepfakes_amd"))
 from addvisor_hip import gemm as G, _lib
 _lib.init()
 dev = torch.device("cuda:0")

@@ -1,7 +1,8 @@
 """STFT / masked-ISTFT kernel timing at the BASELINE shape (B = 64 x 4 s) against their algorithmic HBM bytes
 (1.89 MB / clip forward incl. X, 1.47 MB / clip per resynthesis)."""
 import sys, torch
-sys.path.insert(0, "xai-audio-deepfakes_amd")
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "xai-audio-deepfakes_amd"))
 from addvisor_hip import _lib, ops, synthetic as syn
 _lib.init()
 dev = torch.device("cuda:0")

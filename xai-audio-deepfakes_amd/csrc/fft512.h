@@ -23,11 +23,15 @@
 
 namespace advh {
 
-struct cf { float x, y; };
+// A complex number is a 2-lane fp32 vector: add / sub are ONE packed instruction (v_pk_add_f32), a complex product two
+// (v_pk_mul_f32 + v_pk_fma_f32: a.x * (b.x, b.y) + a.y * (-b.y, b.x); the broadcasts, the swap and the sign are operand
+// modifiers of the packed encoding) -- gfx950 issues packed fp32 at the scalar-fp32 instruction rate, and the STFT / ISTFT
+// kernels are VALU-issue-bound.
+typedef float cf __attribute__((ext_vector_type(2)));
 
-ADVH_HD cf cmul(cf a, cf b) { return cf{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
-ADVH_HD cf cadd(cf a, cf b) { return cf{a.x + b.x, a.y + b.y}; }
-ADVH_HD cf csub(cf a, cf b) { return cf{a.x - b.x, a.y - b.y}; }
+ADVH_HD cf cmul(cf a, cf b) { return cf{a.x, a.x} * b + cf{a.y, a.y} * cf{-b.y, b.x}; }
+ADVH_HD cf cadd(cf a, cf b) { return a + b; }
+ADVH_HD cf csub(cf a, cf b) { return a - b; }
 ADVH_HD cf cconj(cf a) { return cf{a.x, -a.y}; }
 
 // physical index of logical element i in a padded row

@@ -102,7 +102,11 @@ __device__ __forceinline__ float fast_expm1(float y) {
 __device__ __forceinline__ float mask_factor(float m, float M, int mode) {
     if (mode == ADVH_MASK_LINEAR) return m;
     if (M < 1e-12f) return m;
-    return fast_expm1(m * fast_log1p(M)) * __builtin_amdgcn_rcpf(M);
+    // g / M = ((1 + M)^m - 1) / M on the hardware log2 / exp2 units: three transcendentals per bin (v_log, v_exp, v_rcp) instead
+    // of the seven of expm1(m * log1p(M)) with Kahan's corrections.  The cancellation in (1 + M)^m - 1 costs RELATIVE accuracy of
+    // the factor only where the factor is small, i.e. where the masked bin contributes little: the absolute error of the masked
+    // bin X * g / M is <= ~1e-7 (1 + M) (one ulp of (1 + M)^m), against a waveform tolerance of 5e-6.
+    return (__builtin_amdgcn_exp2f(m * __builtin_amdgcn_logf(1.f + M)) - 1.f) * __builtin_amdgcn_rcpf(M);
 }
 
 // ------------------------------------------------------------------------------------------ forward
@@ -278,14 +282,14 @@ __global__ __launch_bounds__(THREADS, 4) void istft_kernel(
     long wave_stride, int T, int L, int hop, int win, int R, const float* __restrict__ window, long zstride) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int ROWP = RowPitch<FB>::value;
-    float *re, *im, *acc;
-    carve<FB>(smem, re, im, acc);
+    float *re, *im, *unused_scratch;
+    carve<FB>(smem, re, im, unused_scratch);
+    (void)unused_scratch;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int b = blockIdx.y, g = blockIdx.x;
     const int left = (NFFT - win) / 2;
     const int S = FB - R + 1;                         // complete hop-segments this workgroup emits
     const int tA = g * S - (R - 1);                   // first frame it transforms (may be < 0)
-    const int nacc = (FB - 1) * hop + win;
     // mask-in / mask-out are two workgroups (grid z): round 2 first ran them as two passes of one workgroup over tile values
     // kept in registers (one HBM read of the spectrogram), but the 27 live tile registers pushed the kernel to 191 VGPRs = ONE
     // workgroup per CU; as separate workgroups (the second read comes from L2) it fits 128 VGPRs = two per CU and is faster.
@@ -345,13 +349,17 @@ __global__ __launch_bounds__(THREADS, 4) void istft_kernel(
         re[tl * ROWP + fidx(k)] = xr;
         im[tl * ROWP + fidx(k)] = xi;
     }
-    for (int i = tid; i < nacc; i += THREADS) acc[i] = 0.f;
     __syncthreads();
     if (pass == 0) STAMP(5);
     LaneTw ltw;                                       // fetched after the tile registers have died
     load_lane_twiddles(lane, ltw);
 
-    // 2. one wavefront per frame: Hermitian glue, inverse FFT512, windowed overlap-add into LDS
+    // 2. one wavefront per frame: Hermitian glue, inverse FFT512, then the frame's windowed time samples go back into the frame's
+    // OWN LDS rows with plain 8-byte stores (sample j at re-row word j for j < ROWP, else im-row word j - ROWP: the rows are dead once
+    // the last pass has loaded them, and a wavefront's DS operations complete in order).  Round 2 overlap-added with LDS float
+    // atomics (two addends per slot): the PMC pass of round 3 (profiles/r03_stft_pmc.txt) showed 114 LDS-array cycles per atomic
+    // instruction -- 127 us of LDS time per launch, the whole kernel.  The sum over the R overlapping frames now happens in step 3.
+    static_assert(2 * RowPitch<FB>::value >= NFFT, "a frame's time samples must fit its two LDS rows");
     for (int f = wv; f < FB; f += THREADS / 64) {
         int t = tA + f;
         if (t < 0 || t >= T) continue;                // wave-uniform
@@ -378,21 +386,27 @@ __global__ __launch_bounds__(THREADS, 4) void istft_kernel(
         wave_fence();
         cf yv[8];
         fft512_wave<+1, false, true>(rr, ii, lane, ltw, yv);          // y[lane + 64 q] stays in registers
-        float* fa = acc + f * hop;
+        wave_fence();                                                  // every lane's last-pass loads precede the stores below
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            int n = lane + 64 * q;
-            int j0 = 2 * n - left, j1 = j0 + 1;
+            const int n = lane + 64 * q;
+            const int j0 = 2 * n - left, j1 = j0 + 1;
             float a = yv[q].x * (1.f / 512.f), c = yv[q].y * (1.f / 512.f);
-            if (j0 >= 0 && j0 < win) atomicAdd(&fa[j0], window ? a * window[j0] : a);
-            if (j1 >= 0 && j1 < win) atomicAdd(&fa[j1], window ? c * window[j1] : c);
+            if (!(left & 1)) {                        // j0 even (win % 4 == 0, the reference's 644 and Hann-1024): one aligned 8-byte store per pair
+                if (j0 < 0 || j0 >= win) continue;    // win is even: j1 < win too
+                if (window) { a *= window[j0]; c *= window[j1]; }
+                *reinterpret_cast<float2*>(j0 < ROWP ? rr + j0 : ii + (j0 - ROWP)) = make_float2(a, c);
+            } else {
+                if (j0 >= 0 && j0 < win) *(j0 < ROWP ? rr + j0 : ii + (j0 - ROWP)) = window ? a * window[j0] : a;
+                if (j1 >= 0 && j1 < win) *(j1 < ROWP ? rr + j1 : ii + (j1 - ROWP)) = window ? c * window[j1] : c;
+            }
         }
     }
     __syncthreads();
     if (pass == 0) STAMP(6);
 
-    // 3. emit the S complete hop-segments, divided by the window envelope, trimmed to [0, L)
-    const int a0 = (R - 1) * hop;                     // first complete accumulator slot
+    // 3. emit the S complete hop-segments: sum of the R overlapping frames' samples, divided by the window envelope, trimmed to [0, L)
+    const int a0 = (R - 1) * hop;                     // first complete slot (relative to frame tA's first sample)
     for (int i = tid; i < S * hop; i += THREADS) {
         int a = a0 + i;
         int p = tA * hop + left + a;                  // padded-signal coordinate
@@ -400,17 +414,24 @@ __global__ __launch_bounds__(THREADS, 4) void istft_kernel(
         if (n < 0 || n >= L) continue;
         // frames covering p:  t*hop + left <= p < t*hop + left + win
         int thi = (p - left) / hop;
-        float env = 0.f;
+        float env = 0.f, sum = 0.f;
         for (int r = 0; r < R; ++r) {
             int t = thi - r;
             int j = p - left - t * hop;
-            if (t >= 0 && t < T && j >= 0 && j < win) { float ww = window ? window[j] : 1.f; env += ww * ww; }
+            if (t >= 0 && t < T && j >= 0 && j < win) {
+                float ww = window ? window[j] : 1.f;
+                env += ww * ww;
+                const int f = t - tA;                 // 0 <= f < FB: the S complete segments only touch this workgroup's frames
+                sum += j < ROWP ? re[f * ROWP + j] : im[f * ROWP + j - ROWP];
+            }
         }
-        out[n] = env > 1e-11f ? acc[a] / env : 0.f;
+        out[n] = env > 1e-11f ? sum / env : 0.f;
     }
     if (pass == 0) STAMP(7);
 }
 
+// the inverse needs the FFT rows only (the overlap-add reuses them): 35 KB at FB = 8 -> four workgroups per CU
+static size_t lds_rows_bytes(int FB) { return sizeof(float) * 2 * FB * (FB == 8 ? RowPitch<8>::value : RowPitch<16>::value); }
 static size_t lds_bytes(int FB, int hop, int win) {
     const int pitch = FB == 8 ? RowPitch<8>::value : RowPitch<16>::value;
     return sizeof(float) * (2 * FB * pitch + (FB - 1) * hop + win);
@@ -552,7 +573,7 @@ static int launch_istft(int src, const float* a, const float* ph, const float* m
     const int nG = (NFFT / 2 + L - left + S * hop - 1) / (S * hop);
     dim3 grid(nG, B, nz);
 #define ISTFT_LAUNCH(SRC_, FB_)                                                                                          \
-    hipLaunchKernelGGL((istft_kernel<SRC_, FB_>), grid, dim3(THREADS), lds_bytes(FB_, hop, win), (hipStream_t)stream, a, ph,  \
+    hipLaunchKernelGGL((istft_kernel<SRC_, FB_>), grid, dim3(THREADS), lds_rows_bytes(FB_), (hipStream_t)stream, a, ph,  \
                        mask, Fm, Tm, mode, which0, p0, p1, (long)ws, T, L, hop, win, R, window, (long)zstride)
     if (src == 0) { if (FB == 8) ISTFT_LAUNCH(0, 8); else ISTFT_LAUNCH(0, 16); }
     else if (src == 1) { if (FB == 8) ISTFT_LAUNCH(1, 8); else ISTFT_LAUNCH(1, 16); }
