@@ -187,6 +187,19 @@ __global__ __launch_bounds__(THREADS, 6) void stft_fwd_kernel(
             const int s0 = (tA + f) * hop + left - NFFT / 2;      // clip sample under window position 0 (before reflection)
             const int nmax = min(n_in, L);
             float xa[8], xc[8], wa[8], wc[8];
+            // interior frames (all but the first two / last two of a clip): no reflection, no tail -- the window's samples are the
+            // contiguous run w[s0 .. s0 + win), one aligned 8-byte load per (j0, j0 + 1) pair and no index arithmetic beyond the
+            // window test (wave-uniform branch; ~200 of the kernel's ~800 VALU instructions per frame were reflect / clamp logic)
+            const bool interior = s0 >= 0 && s0 + win <= nmax && !window && !(left & 1) && !(s0 & 1) && !(wave_stride & 1);
+            if (interior) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int j0 = 2 * (lane + 64 * q) - left;
+                    const bool ok = j0 >= 0 && j0 < win;          // win even: j0 + 1 < win too
+                    const float2 v = ok ? *reinterpret_cast<const float2*>(w + s0 + j0) : make_float2(0.f, 0.f);
+                    zv[q] = cf{v.x, v.y};
+                }
+            } else {
 #pragma unroll
             for (int q = 0; q < 8; ++q) {             // all loads first (predicated), arithmetic afterwards
                 const int n = lane + 64 * q;
@@ -204,6 +217,7 @@ __global__ __launch_bounds__(THREADS, 6) void stft_fwd_kernel(
             }
 #pragma unroll
             for (int q = 0; q < 8; ++q) zv[q] = cf{xa[q] * wa[q], xc[q] * wc[q]};
+            }
         }
         fft512_wave<-1, true, false>(rr, ii, lane, ltw, zv);
         cf A[4], Bv[4];
@@ -406,26 +420,26 @@ __global__ __launch_bounds__(THREADS, 4) void istft_kernel(
     if (pass == 0) STAMP(6);
 
     // 3. emit the S complete hop-segments: sum of the R overlapping frames' samples, divided by the window envelope, trimmed to [0, L)
-    const int a0 = (R - 1) * hop;                     // first complete slot (relative to frame tA's first sample)
-    for (int i = tid; i < S * hop; i += THREADS) {
-        int a = a0 + i;
-        int p = tA * hop + left + a;                  // padded-signal coordinate
-        int n = p - NFFT / 2;
-        if (n < 0 || n >= L) continue;
-        // frames covering p:  t*hop + left <= p < t*hop + left + win
-        int thi = (p - left) / hop;
-        float env = 0.f, sum = 0.f;
-        for (int r = 0; r < R; ++r) {
-            int t = thi - r;
-            int j = p - left - t * hop;
-            if (t >= 0 && t < T && j >= 0 && j < win) {
-                float ww = window ? window[j] : 1.f;
-                env += ww * ww;
-                const int f = t - tA;                 // 0 <= f < FB: the S complete segments only touch this workgroup's frames
-                sum += j < ROWP ? re[f * ROWP + j] : im[f * ROWP + j - ROWP];
+    // Segment s (s = 0 .. S-1) holds the hop samples u = 0 .. hop-1 at padded coordinate p = (tA + R - 1 + s) * hop + left + u; exactly
+    // the frames t = tA + R - 1 + s - r, r = 0 .. R-1, cover it, each with its sample j = u + r * hop: no division per sample.
+    for (int sgm = 0; sgm < S; ++sgm) {
+        const int thi = tA + R - 1 + sgm;
+        const int n0 = thi * hop + left - NFFT / 2;   // clip sample of u = 0
+        for (int u = tid; u < hop; u += THREADS) {
+            const int n = n0 + u;
+            if (n < 0 || n >= L) continue;
+            float env = 0.f, sum = 0.f;
+            for (int r = 0; r < R; ++r) {
+                const int t = thi - r, j = u + r * hop;
+                if (t >= 0 && t < T && j < win) {
+                    const float ww = window ? window[j] : 1.f;
+                    env += ww * ww;
+                    const int f = t - tA;             // 0 <= f < FB
+                    sum += j < ROWP ? re[f * ROWP + j] : im[f * ROWP + j - ROWP];
+                }
             }
+            out[n] = env > 1e-11f ? sum / env : 0.f;
         }
-        out[n] = env > 1e-11f ? sum / env : 0.f;
     }
     if (pass == 0) STAMP(7);
 }
@@ -522,10 +536,10 @@ extern "C" int advh_stft_forward(const float* wave, int64_t wave_stride, int n_i
     dim3 grid((T + FB - 1) / FB, B);
     const AdjArgs none = {nullptr, nullptr, 0, 0, 0, 0};
     if (FB == 8)
-        hipLaunchKernelGGL((stft_fwd_kernel<8, 0>), grid, dim3(THREADS), lds_bytes(8, hop, win), (hipStream_t)stream, wave,
+        hipLaunchKernelGGL((stft_fwd_kernel<8, 0>), grid, dim3(THREADS), lds_rows_bytes(8), (hipStream_t)stream, wave,     // the plain forward stages no samples: rows only
                            (long)wave_stride, n_in, L, hop, win, window, X, mag, phase, T, none);
     else
-        hipLaunchKernelGGL((stft_fwd_kernel<16, 0>), grid, dim3(THREADS), lds_bytes(16, hop, win), (hipStream_t)stream, wave,
+        hipLaunchKernelGGL((stft_fwd_kernel<16, 0>), grid, dim3(THREADS), lds_rows_bytes(16), (hipStream_t)stream, wave,
                            (long)wave_stride, n_in, L, hop, win, window, X, mag, phase, T, none);
     return hipGetLastError() == hipSuccess ? ADVH_OK : ADVH_ELAUNCH;
 }
