@@ -76,22 +76,40 @@ __global__ __launch_bounds__(256) void mrf_mix_kernel(const _Float16* __restrict
     }
 }
 
-// conv_post: Conv1d(C -> 1, k, "same") + tanh on a pre-activated zero-haloed map; wav [B][1][T] fp32
+// conv_post: Conv1d(C -> 1, k, "same") + tanh on a pre-activated zero-haloed map; wav [B][1][T] fp32.
+// One workgroup = 256 consecutive output samples of one clip: the 256 + k - 1 rows they touch are staged ONCE in LDS as fp32
+// (plain fp16 rows or joined split planes), pitch C + 4 words so that the per-thread float4 reads of consecutive rows are
+// conflict-free; every thread then runs its k * C multiply-adds out of LDS with the weights in scalar registers.  (Round 2's
+// form -- every thread loading its own k rows from global memory, both planes in the fp32-class mode -- took 6.75 ms per 256-clip
+// batch, 13x its HBM time: profiles/r03_hifigan_f32_kernel_summary.txt.)
+constexpr int CP_TO = 256, CP_MAXK = 15;
 __global__ __launch_bounds__(256) void conv_post_kernel(const _Float16* __restrict__ x, const float* __restrict__ w /*[k][C]*/,
-                                                        float bias, float* __restrict__ wav, int C, int T, int halo, int k, long total,
-                                                        long x_lo) {
-    long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= total) return;
-    int t = (int)(i % T), b = (int)(i / T);
-    const long p = ((long)b * (T + 2 * halo) + t + halo - (k - 1) / 2) * C;
-    float acc = bias;
-    for (int j = 0; j < k * C; j += 8) {
-        float v[8];
-        load_h_rt<8>(x, p + j, x_lo, v);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) acc = fmaf(v[e], w[j + e], acc);
+                                                        float bias, float* __restrict__ wav, int C, int T, int halo, int k, long x_lo) {
+    extern __shared__ __attribute__((aligned(16))) float xs[];            // [CP_TO + k - 1][C + 4]
+    const int tid = threadIdx.x, b = blockIdx.y, t0 = blockIdx.x * CP_TO;
+    const int pitch = C + 4, rows = CP_TO + k - 1, ch = C / 8;
+    const long P = T + 2 * halo;
+    const long r0 = (long)b * P + t0 + halo - (k - 1) / 2;                // map row under tap 0 of output t0 (always inside the clip's padded rows)
+    for (int i = tid; i < rows * ch; i += 256) {
+        const int row = i / ch, c = i % ch;
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (t0 + row < T + (k - 1)) load_h_rt<8>(x, (r0 + row) * C + c * 8, x_lo, v);     // rows past the clip's halo only feed outputs t >= T
+        *(float4*)(xs + row * pitch + c * 8) = make_float4(v[0], v[1], v[2], v[3]);
+        *(float4*)(xs + row * pitch + c * 8 + 4) = make_float4(v[4], v[5], v[6], v[7]);
     }
-    wav[i] = tanhf(acc);
+    __syncthreads();
+    const int t = t0 + tid;
+    if (t >= T) return;
+    float acc = bias;
+    for (int j = 0; j < k; ++j) {
+        const float* xr = xs + (tid + j) * pitch;
+        const float* wr = w + j * C;                                       // uniform: scalar loads
+        for (int c = 0; c < C; c += 4) {
+            const float4 xv = *(const float4*)(xr + c);
+            acc = fmaf(xv.x, wr[c], acc); acc = fmaf(xv.y, wr[c + 1], acc); acc = fmaf(xv.z, wr[c + 2], acc); acc = fmaf(xv.w, wr[c + 3], acc);
+        }
+    }
+    wav[(long)b * T + t] = tanhf(acc);
 }
 
 // log-mel: out[b][m][t] = log(max(sum_f fb[f][m] * mag[b][f][t], 1e-5))   (hifigan.py:163-178)
@@ -171,9 +189,11 @@ extern "C" int advh_hifigan_mrf_mix_split(const void* a, const void* b, const vo
 static int conv_post_launch(const void* x, int64_t x_lo, const float* w, float bias, float* wav, int B, int C, int T, int halo, int k,
                             advh_stream_t stream) {
     if (!x || !w || !wav || B <= 0 || C <= 0 || C % 8 || T <= 0 || k <= 0 || !(k & 1) || halo < (k - 1) / 2 || x_lo < 0) return ADVH_EINVAL;
-    long total = (long)B * T;
-    hipLaunchKernelGGL(conv_post_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const _Float16*)x, w,
-                       bias, wav, C, T, halo, k, total, (long)x_lo);
+    if (k > CP_MAXK || C > 64) return ADVH_EUNSUPPORTED;
+    const size_t lds = (size_t)(CP_TO + k - 1) * (C + 4) * sizeof(float);
+    if (lds > 64 * 1024 && advh_ensure_lds((const void*)conv_post_kernel) != ADVH_OK) return ADVH_ELAUNCH;
+    hipLaunchKernelGGL(conv_post_kernel, dim3((unsigned)((T + CP_TO - 1) / CP_TO), B), dim3(256), lds, (hipStream_t)stream, (const _Float16*)x, w,
+                       bias, wav, C, T, halo, k, (long)x_lo);
     return ADVH_LAUNCH_CHECK();
 }
 
