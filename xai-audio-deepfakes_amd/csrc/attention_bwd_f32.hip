@@ -49,10 +49,10 @@ __device__ __forceinline__ float4 grow4(const _Float16* base, long lo, long row_
 }
 
 // rows [0, T) x channels [0, dm) of a split-format matrix (row stride ld) -> fp32 LDS tile [NKEY][D + 4], zero elsewhere
-template <int NKEY, int D>
+template <int NKEY, int D, int NTH>
 __device__ __forceinline__ void stage_f32(float* dst, const _Float16* src, long lo, long ld, int T, int dm, int tid) {
     constexpr int PITCH = D + 4, CH = D / 8;
-    for (int i = tid; i < NKEY * CH; i += 256) {
+    for (int i = tid; i < NKEY * CH; i += NTH) {
         const int row = i / CH, c = i % CH;
         float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (row < T && c * 8 < dm) load_h_rt<8>(src, (long)row * ld + c * 8, lo, v);
@@ -69,8 +69,11 @@ struct AttBwdF32 {
     static constexpr int LDS_BYTES = ((TWO ? 2 : 1) * MAT + 3 * NKEY) * 4;
 };
 
-template <int NT, int D>
-__global__ __launch_bounds__(256) void attention_bwd_f32_kernel(const _Float16* __restrict__ qkv, long qkv_lo, const _Float16* __restrict__ dctx,
+// NW wavefronts per workgroup: 8 (two per SIMD, <= 256 VGPRs each) where the register budget allows -- head dims <= 64 --, so that
+// one wavefront's LDS / global latency and MFMA dependency stalls are covered by the other's issue (one workgroup per CU: the
+// staged matrices take most of the LDS); 4 for head dim 128.
+template <int NT, int D, int NW>
+__global__ __launch_bounds__(64 * NW) void attention_bwd_f32_kernel(const _Float16* __restrict__ qkv, long qkv_lo, const _Float16* __restrict__ dctx,
                                                                 long dctx_lo, _Float16* __restrict__ dqkv, long dqkv_lo, int T, int H, int dm,
                                                                 float scale) {
     typedef AttBwdF32<NT, D> G;
@@ -92,12 +95,12 @@ __global__ __launch_bounds__(256) void attention_bwd_f32_kernel(const _Float16* 
     _Float16* dbase = dqkv + (long)b * T * ld + head * dm;
     const float c2 = scale * LOG2E_F;
 
-    stage_f32<NKEY, D>(M0, base + H, qkv_lo, ld, T, dm, tid);
-    if (TWO) stage_f32<NKEY, D>(M1, base + 2 * H, qkv_lo, ld, T, dm, tid);
+    stage_f32<NKEY, D, 64 * NW>(M0, base + H, qkv_lo, ld, T, dm, tid);
+    if (TWO) stage_f32<NKEY, D, 64 * NW>(M1, base + 2 * H, qkv_lo, ld, T, dm, tid);
     __syncthreads();
 
     // ------------------------------------------------------------------ pass A: query tiles
-    for (int qt = wv; qt * 16 < T; qt += 4) {
+    for (int qt = wv; qt * 16 < T; qt += NW) {
         const int qrow = qt * 16 + fr, qr = qrow < T ? qrow : T - 1;
         float4 qf[DG], of[DG];
 #pragma unroll
@@ -179,10 +182,10 @@ __global__ __launch_bounds__(256) void attention_bwd_f32_kernel(const _Float16* 
     __syncthreads();
 
     // ------------------------------------------------------------------ pass B: key tiles
-    stage_f32<NKEY, D>(M0, base, qkv_lo, ld, T, dm, tid);                 // Q
-    if (TWO) stage_f32<NKEY, D>(M1, dob, dctx_lo, (long)H, T, dm, tid);   // dO
+    stage_f32<NKEY, D, 64 * NW>(M0, base, qkv_lo, ld, T, dm, tid);                 // Q
+    if (TWO) stage_f32<NKEY, D, 64 * NW>(M1, dob, dctx_lo, (long)H, T, dm, tid);   // dO
     __syncthreads();
-    for (int kt = wv; kt * 16 < T; kt += 4) {
+    for (int kt = wv; kt * 16 < T; kt += NW) {
         const int krow = kt * 16 + fr, kr_ = krow < T ? krow : T - 1;
         float4 kf[DG], vf[DG];
 #pragma unroll
@@ -244,9 +247,9 @@ __global__ __launch_bounds__(256) void attention_bwd_f32_kernel(const _Float16* 
 
     // ------------------------------------------------------------------ pass B2 (one matrix fits): dO staged, dV^T = dO^T P
     __syncthreads();
-    stage_f32<NKEY, D>(M0, dob, dctx_lo, (long)H, T, dm, tid);
+    stage_f32<NKEY, D, 64 * NW>(M0, dob, dctx_lo, (long)H, T, dm, tid);
     __syncthreads();
-    for (int kt = wv; kt * 16 < T; kt += 4) {
+    for (int kt = wv; kt * 16 < T; kt += NW) {
         const int krow = kt * 16 + fr, kr_ = krow < T ? krow : T - 1;
         float4 kf[DG];
 #pragma unroll
@@ -291,8 +294,9 @@ static int launch_att_bwd_f32(const void* qkv, long qkv_lo, const void* dctx, lo
                               int heads, int dm, float scale, hipStream_t s) {
     constexpr int lds = AttBwdF32<NT, D>::LDS_BYTES;
     static_assert(lds <= 160 * 1024, "one staged matrix must fit");
-    if (advh_ensure_lds((const void*)attention_bwd_f32_kernel<NT, D>) != ADVH_OK) return ADVH_ELAUNCH;
-    hipLaunchKernelGGL((attention_bwd_f32_kernel<NT, D>), dim3(heads, B), dim3(256), lds, s, (const _Float16*)qkv, qkv_lo,
+    constexpr int NW = D <= 64 ? 8 : 4;
+    if (advh_ensure_lds((const void*)attention_bwd_f32_kernel<NT, D, NW>) != ADVH_OK) return ADVH_ELAUNCH;
+    hipLaunchKernelGGL((attention_bwd_f32_kernel<NT, D, NW>), dim3(heads, B), dim3(64 * NW), lds, s, (const _Float16*)qkv, qkv_lo,
                        (const _Float16*)dctx, dctx_lo, (_Float16*)dqkv, dqkv_lo, T, H, dm, scale);
     return ADVH_LAUNCH_CHECK();
 }
