@@ -361,7 +361,7 @@ int advh_time_mask(const float* attr, float* mask, float* wave_in, float* wave_o
 /* RANGE of the split format: hi is an fp16, so a value must satisfy |x| <= 65504 (the reference's fp32: 3.4e38).  Every kernel
  * that WRITES a split tensor saturates a larger value (hi = +-65504, lo = the clamped remainder) instead of producing inf /
  * NaN planes, and raises a sticky process-wide flag in host-mapped memory.  advh_split_overflow returns the flag (1 = some
- * kernel that has already run met an out-of-range or NaN value since the last reset) and clears it when reset != 0; it reads
+ * kernel that has already run met an out-of-range value, +-inf included, since the last reset; a NaN passes through as NaN planes) and clears it when reset != 0; it reads
  * host memory only -- no synchronisation -- so a kernel still in flight is seen by a later call.  Weights are range-checked
  * on the host when they are packed.                                                                                     */
 int advh_split_overflow(int reset);

@@ -142,7 +142,7 @@ def lib() -> C.CDLL:
 
 
 class SplitRangeError(AdvhError, FloatingPointError):
-    """A kernel of the fp32-class mode met a value outside the split format's range (|x| > 65504, or NaN)."""
+    """A kernel of the fp32-class mode met a value outside the split format's range (|x| > 65504)."""
 
 
 def check_overflow(what: str = "") -> None:
@@ -150,7 +150,7 @@ def check_overflow(what: str = "") -> None:
     not synchronise, so it reports kernels that have ALREADY run -- call after a synchronisation point for a definite answer."""
     if _lib is not None and _lib.advh_split_overflow(1):
         raise SplitRangeError((what + ": " if what else "") + "a value left the fp32-class format's range (|x| > 65504 between two "
-                              "matrix products, or NaN): the split planes saturated.  Scale the input / weights, or run precision='f16' "
+                              "matrix products): the split planes saturated.  Scale the input / weights, or run precision='f16' "
                               "diagnostics; the reference's fp32 has no such limit (include/addvisor_hip.h, advh_split_overflow)")
 
 

@@ -346,8 +346,8 @@ __global__ __launch_bounds__(512, 1) void attention_x3_kernel(const _Float16* __
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 _Float16 h0, l0, h1 = (_Float16)0.f, l1 = (_Float16)0.f;
-                split_f32(s[2 * ss][r] * inv, h0, l0);
-                if (2 * ss + 1 < NT) split_f32(s[(2 * ss + 1 < NT) ? 2 * ss + 1 : 0][r] * inv, h1, l1);
+                split_f32_raw(s[2 * ss][r] * inv, h0, l0);
+                if (2 * ss + 1 < NT) split_f32_raw(s[(2 * ss + 1 < NT) ? 2 * ss + 1 : 0][r] * inv, h1, l1);
                 ph[ss][r] = h0; pl_[ss][r] = l0; ph[ss][4 + r] = h1; pl_[ss][4 + r] = l1;
             }
         f32x4 om[DT], ox[DT];
@@ -497,8 +497,8 @@ __global__ __launch_bounds__(512, 1) void attention_x3_stream_kernel(const _Floa
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     _Float16 h0, l0, h1 = (_Float16)0.f, l1 = (_Float16)0.f;
-                    split_f32(s[2 * ss][r], h0, l0);
-                    if (2 * ss + 1 < NTB) split_f32(s[(2 * ss + 1 < NTB) ? 2 * ss + 1 : 0][r], h1, l1);
+                    split_f32_raw(s[2 * ss][r], h0, l0);
+                    if (2 * ss + 1 < NTB) split_f32_raw(s[(2 * ss + 1 < NTB) ? 2 * ss + 1 : 0][r], h1, l1);
                     ph[ss][r] = h0; pl_[ss][r] = l0; ph[ss][4 + r] = h1; pl_[ss][4 + r] = l1;
                 }
 #pragma unroll
@@ -614,8 +614,8 @@ __global__ __launch_bounds__(512, 1) void attention_x3_tr_kernel(const _Float16*
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 _Float16 h0, l0, h1 = (_Float16)0.f, l1 = (_Float16)0.f;
-                split_f32(s[2 * ss][r] * inv, h0, l0);
-                if (2 * ss + 1 < NT) split_f32(s[(2 * ss + 1 < NT) ? 2 * ss + 1 : 0][r] * inv, h1, l1);
+                split_f32_raw(s[2 * ss][r] * inv, h0, l0);
+                if (2 * ss + 1 < NT) split_f32_raw(s[(2 * ss + 1 < NT) ? 2 * ss + 1 : 0][r] * inv, h1, l1);
                 ph[ss][r] = h0; pl_[ss][r] = l0; ph[ss][4 + r] = h1; pl_[ss][4 + r] = l1;
             }
         f32x4 om[DT], ox[DT];

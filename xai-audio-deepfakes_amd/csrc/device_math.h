@@ -38,19 +38,43 @@ __device__ __forceinline__ float gelu_fast(float x) { return 0.5f * x * (1.f + f
 // A value beyond that SATURATES (hi = +-65504, lo = the clamped remainder: x up to +-65535.98 is still exact) instead of
 // turning into inf / NaN downstream, and raises the library's sticky range flag -- one host-mapped word the device writes
 // and the host reads without synchronising (advh_split_overflow; the Python binding turns it into an error at its next call).
-// NaN inputs raise the flag too (their planes are unspecified finite values).
+// A NaN passes through as NaN planes (visible to any isfinite check downstream); +-inf saturates and raises the flag.
 constexpr float SPLIT_LO_SCALE = 2048.f, SPLIT_LO_INV = 1.f / 2048.f, SPLIT_MAX = 65504.f;
 static __constant__ int* g_split_flag = nullptr;     // this translation unit's copy of the flag pointer (set by advh_init); constant
                                                      // address space: the load is scalar and never ordered against the epilogue's stores
+// unchecked conversion: for values that are in range by construction (softmax probabilities, ...)
+__device__ __forceinline__ void split_f32_raw(float x, _Float16& hi, _Float16& lo) {
+    _Float16 h = (_Float16)x;
+    if (fabsf(x) < 6.103515625e-05f) h = (_Float16)0.f;
+    hi = h;
+    lo = (_Float16)((x - (float)h) * SPLIT_LO_SCALE);
+}
+// saturating conversion + sticky flag (the rare path of the vector form below, and scalar call sites)
 __device__ __forceinline__ void split_f32(float x, _Float16& hi, _Float16& lo) {
-    // branch-free value path (the in-range result is bit-identical to the unclamped form): two v_med3 per value
     _Float16 h = (_Float16)__builtin_amdgcn_fmed3f(x, -SPLIT_MAX, SPLIT_MAX);
     if (fabsf(x) < 6.103515625e-05f) h = (_Float16)0.f;
     hi = h;
     lo = (_Float16)__builtin_amdgcn_fmed3f((x - (float)h) * SPLIT_LO_SCALE, -SPLIT_MAX, SPLIT_MAX);
-    if (!(fabsf(x) <= SPLIT_MAX)) {                  // out of range, or NaN: one exec-masked store on a path that is never taken in range
+    if (fabsf(x) > SPLIT_MAX) {                      // out of range: one exec-masked store on a path that is never taken in range
         int* f = g_split_flag;
         if (f) *(volatile int*)f = 1;
+    }
+}
+// VW values at once (the epilogues convert 4 or 8 consecutive channels per lane): ONE range test on max|v| in front of the
+// unchecked conversions -- ~1 extra VALU instruction per value instead of the 3-4 of a per-value clamp + test (round 3: the
+// per-value form cost 5 % of gemm_x3_kernel's launch time) -- and the saturating form only when some lane is out of range.
+// (NaN does not win a max: NaN values pass through as NaN planes, unflagged; inf is flagged and saturates.)
+template <int VW, typename HV>
+__device__ __forceinline__ void split_f32_vec(const float (&v)[VW], HV& hv, HV& lv) {
+    float m = fabsf(v[0]);
+#pragma unroll
+    for (int r = 1; r < VW; ++r) m = fmaxf(m, fabsf(v[r]));
+    if (m > SPLIT_MAX) {
+#pragma unroll
+        for (int r = 0; r < VW; ++r) { _Float16 h, l; split_f32(v[r], h, l); hv[r] = h; lv[r] = l; }
+    } else {
+#pragma unroll
+        for (int r = 0; r < VW; ++r) { _Float16 h, l; split_f32_raw(v[r], h, l); hv[r] = h; lv[r] = l; }
     }
 }
 // defines this translation unit's setter of g_split_flag (called by advh_init on every device it initialises)
@@ -67,8 +91,7 @@ __device__ __forceinline__ void store_h_rt(_Float16* base, long o, long lo_off, 
     typedef _Float16 hvec __attribute__((ext_vector_type(VW)));
     hvec hv, lv;
     if (lo_off) {
-#pragma unroll
-        for (int r = 0; r < VW; ++r) { _Float16 h, l; split_f32(v[r], h, l); hv[r] = h; lv[r] = l; }
+        split_f32_vec<VW>(v, hv, lv);
         *(hvec*)(base + o) = hv;
         *(hvec*)(base + o + lo_off) = lv;
     } else {

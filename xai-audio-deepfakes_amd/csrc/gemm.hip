@@ -80,8 +80,7 @@ __device__ __forceinline__ void store_h(void* base, long o, long o_lo, const flo
     typedef _Float16 hvec __attribute__((ext_vector_type(VW)));
     if constexpr (SPLIT) {
         hvec hv, lv;
-#pragma unroll
-        for (int r = 0; r < VW; ++r) { _Float16 h, l; split_f32(v[r], h, l); hv[r] = h; lv[r] = l; }
+        split_f32_vec<VW>(v, hv, lv);
         *(hvec*)((_Float16*)base + o) = hv;
         *(hvec*)((_Float16*)base + o + o_lo) = lv;
     } else {
@@ -339,10 +338,10 @@ __device__ __forceinline__ void gemm_epilogue_staged(const advh_gemm_desc& p, f3
             }
             char* dst = stage + r * 128 + (((q * 4 + fq) ^ (r & 7)) << 4);
             f16x8 hv, lv;
+            if constexpr (SPLIT) split_f32_vec<8>(v, hv, lv);
+            else {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                if constexpr (SPLIT) { _Float16 h, l; split_f32(v[k], h, l); hv[k] = h; lv[k] = l; }
-                else hv[k] = (_Float16)v[k];
+                for (int k = 0; k < 8; ++k) hv[k] = (_Float16)v[k];
             }
             *(f16x8*)dst = hv;
             if constexpr (SPLIT) *(f16x8*)(dst + PL) = lv;
