@@ -367,8 +367,7 @@ def explain_line(ctx):
         "roofline": head["roofline"],
         "cpu_baseline": None,
     }
-    if rank == 0:
-        line["roofline_hbm"] = stft_roofline(ctx["dev"], B)
+    line["roofline_hbm"] = stft_roofline(ctx["dev"], B)        # every rank runs it (identical, a few ms): no rank leaves the others waiting
     extras = world == 1 and not args.no_extras and not args.tune
     if rank == 0 and world == 1 and not args.no_traffic and not args.tune and head["roofline"]["launches"]:
         kern = head["roofline"]["kernel"]
