@@ -44,9 +44,7 @@ const char* advh_version(void);
 int advh_init(void);
 
 /* Tuning knobs (process-wide, not thread-safe; set before launching work):
- *   "stft_frames_per_workgroup" = 8 (default) | 16 : STFT / ISTFT frames per workgroup;
- *   "x3_persist_slots" = 0 (default: one tile per workgroup) | N, a multiple of 8: launch the fp32-class GEMM with N persistent
- *                        workgroups that walk the tile list (measurement switch, profiles/r03_x3_persistent.txt). */
+ *   "stft_frames_per_workgroup" = 8 (default) | 16 : STFT / ISTFT frames per workgroup. */
 int advh_set_option(const char* name, int value);
 
 /* ---------------------------------------------------------------------------------------------

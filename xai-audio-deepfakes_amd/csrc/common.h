@@ -6,7 +6,6 @@
 // Per-module one-time initialisation (dynamic-LDS attributes); defined in gemm.hip.
 int advh_init_rest();
 int advh_init_attention();   // attention.hip
-int advh_gemm_set_x3_persist(int slots);   // gemm.hip: experiment switch behind advh_set_option("x3_persist_slots", n)
 // per-translation-unit setters of the split-format range flag pointer (csrc/device_math.h: ADVH_SPLIT_FLAG_SETTER)
 int advh_split_flag_attention(int* flag);
 int advh_split_flag_attention_bwd_f32(int* flag);

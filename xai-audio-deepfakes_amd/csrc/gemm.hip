@@ -861,7 +861,7 @@ static int launch(const advh_gemm_desc& d, hipStream_t s) {
 // at 1/3 of the fp16 MFMA rate (833 TFLOP/s dense peak) instead of the 157 TFLOP/s of v_mfma_f32_*_f32.
 // 64 KiB of LDS per 128 x 128 K-step and 2 x 64 accumulator registers => two workgroups per CU.
 template <int BM, int BN, int WM, int WN, bool PLAIN>
-__global__ __launch_bounds__(64 * WM * WN, 2) void gemm_x3_kernel(const advh_gemm_desc p, int total_wg) {
+__global__ __launch_bounds__(64 * WM * WN, 2) void gemm_x3_kernel(const advh_gemm_desc p) {
     constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 16, NI = TN / 16;
     constexpr int NT = 64 * WM * WN, RPP = NT / 8;
     constexpr int NA = BM / RPP, NB = BN / RPP;
@@ -881,13 +881,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_x3_kernel(const advh_gem
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wm = wv / WN, wn = wv % WN;
     const int tilesN = (p.N + BN - 1) / BN;
-    // total_wg > 0: PERSISTENT launch -- gridDim.x workgroups walk the total_wg virtual workgroup ids blockIdx.x, + gridDim.x, ...
-    // (gridDim.x a multiple of 8, so a workgroup stays on its XCD and the XCD-aware tile order is unchanged); 0: one tile per workgroup
-    const int nvirt = total_wg > 0 ? total_wg : (int)gridDim.x;
-    for (int vid = blockIdx.x; vid < nvirt; vid += gridDim.x) {
-    if (vid != (int)blockIdx.x) __syncthreads();          // every wavefront has drained the previous tile's staged epilogue out of LDS
-    int nwg = nvirt;
-    int id = vid;
+    int nwg = gridDim.x;
+    int id = blockIdx.x;
     {
         const int q8 = nwg / 8, r8 = nwg % 8, xcd = id % 8;
         id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + id / 8;
@@ -1059,7 +1054,6 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_x3_kernel(const advh_gem
     char* stage = (NI == 4 && MI * 16 * 256 * WM * WN <= 2 * (BM + BN) * BK * 2) ? dsm3 + wv * (MI * 16 * 256) : nullptr;
     if (PLAIN && p.plain_out) gemm_epilogue_plain<MI, NI, true, MI>(p, acc, stage, m0 + wm * TM, n0 + wn * TN, fr, fq, z, p.o_sZ * zh + p.o_sZ2 * zw);
     else gemm_epilogue_rows<MI, NI, true>(p, acc, stage, m0 + wm * TM, n0 + wn * TN, fr, fq, z, p.o_sZ * zh + p.o_sZ2 * zw);
-    }   // virtual workgroup loop
 #ifdef ADVH_STAMPS
     if (blockIdx.x == gridDim.x / 2 && tid == 0) g_gemm_stamps[7] = __builtin_amdgcn_s_memtime();
     if (tid == 0 && blockIdx.x < 16384) g_wg_rec[4 * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime();
@@ -1069,8 +1063,6 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_x3_kernel(const advh_gem
 }
 
 
-static int g_x3_persist = 0;      // 0: one tile per workgroup; N (a multiple of 8): persistent launch with N workgroups
-
 template <int BM, int BN, int WM, int WN>
 static int launch_x3(const advh_gemm_desc& d, hipStream_t s) {
     const int tilesM = (d.M + BM - 1) / BM, tilesN = (d.N + BN - 1) / BN;
@@ -1079,10 +1071,8 @@ static int launch_x3(const advh_gemm_desc& d, hipStream_t s) {
     if (d.z_inner && (long)tilesM * tilesN * nz > 0x7fffffffL) return ADVH_EINVAL;
     dim3 grid(d.z_inner ? tilesM * tilesN * nz : tilesM * tilesN, 1, d.z_inner ? 1 : nz);
     constexpr int lds = 2 * (BM + BN) * BK * 2;
-    int total = 0;
-    if (g_x3_persist > 0 && (int)grid.x > g_x3_persist) { total = (int)grid.x; grid.x = g_x3_persist; }   // experiment switch (advh_set_option "x3_persist_slots")
-    if (d.plain) hipLaunchKernelGGL((gemm_x3_kernel<BM, BN, WM, WN, true>), grid, dim3(64 * WM * WN), lds, s, d, total);
-    else hipLaunchKernelGGL((gemm_x3_kernel<BM, BN, WM, WN, false>), grid, dim3(64 * WM * WN), lds, s, d, total);
+    if (d.plain) hipLaunchKernelGGL((gemm_x3_kernel<BM, BN, WM, WN, true>), grid, dim3(64 * WM * WN), lds, s, d);
+    else hipLaunchKernelGGL((gemm_x3_kernel<BM, BN, WM, WN, false>), grid, dim3(64 * WM * WN), lds, s, d);
     return ADVH_LAUNCH_CHECK();
 }
 
@@ -1107,12 +1097,6 @@ extern "C" int advh_debug_wg_records(long long* out, int n) { return hipMemcpyFr
 extern "C" int advh_debug_kstep(long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_kstep), sizeof(long long) * 8) == hipSuccess ? ADVH_OK : ADVH_ELAUNCH; }
 extern "C" int advh_debug_gemm_stamps(long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gemm_stamps), sizeof(long long) * 8) == hipSuccess ? ADVH_OK : ADVH_ELAUNCH; }
 #endif
-
-int advh_gemm_set_x3_persist(int slots) {          // advh_set_option("x3_persist_slots", n)
-    if (slots < 0 || (slots % 8)) return ADVH_EINVAL;
-    g_x3_persist = slots;
-    return ADVH_OK;
-}
 
 extern "C" int advh_gemm_f16(const advh_gemm_desc* d, int tile, advh_stream_t stream) {
     if (!d || !d->A0 || !d->W || !d->ktab || (!d->out_h && !d->out_f)) return ADVH_EINVAL;

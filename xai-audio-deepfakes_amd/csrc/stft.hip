@@ -470,7 +470,6 @@ extern "C" int advh_set_option(const char* name, int value) {
         g_stft_fb = value;
         return ADVH_OK;
     }
-    if (!strcmp(name, "x3_persist_slots")) return advh_gemm_set_x3_persist(value);
     return ADVH_EINVAL;
 }
 
