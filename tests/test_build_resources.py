@@ -40,3 +40,16 @@ def test_gemm_kernels_do_not_spill():
         assert v["occupancy"] >= 2, (k, v)                     # two co-resident workgroups hide each other's DMA
     main = [v for k, v in f16.items() if "ILi128ELi128ELi2ELi2ELi4E" in k]
     assert main and all(v["occupancy"] >= 4 for v in main), main      # 4 workgroups per CU on the fp16 128x128 tile
+
+
+def test_attention_and_resblock_kernels_do_not_spill():
+    """The fp32-class attention kernels (forward, both head-dim classes, and the fp32 backward) and the fused x3 ResBlock pair:
+    the D = 128 streaming kernel spilled 216 B per lane until round 3 (the staging loop of four planes was unrolled)."""
+    for src, names in (("attention.hip", ("attention_x3_kernel", "attention_x3_stream_kernel")),
+                       ("attention_bwd_f32.hip", ("attention_bwd_f32_kernel",)),
+                       ("resblock_pair_x3.hip", ("resblock_pair_x3_kernel",))):
+        res = resources(src)
+        hit = {k: v for k, v in res.items() if any(n in k for n in names)}
+        assert hit, (src, sorted(res))
+        for k, v in hit.items():
+            assert v["scratch"] == 0, (k, v)

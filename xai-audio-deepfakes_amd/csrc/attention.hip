@@ -424,6 +424,7 @@ __global__ __launch_bounds__(512, 1) void attention_x3_stream_kernel(const _Floa
         for (int blk = 0; blk < nblk; ++blk) {
             const int k0 = blk * KB;
             __syncthreads();                         // every wavefront is done with the previous block
+#pragma unroll 1
             for (int pl = 0; pl < 4; ++pl) {         // K hi, K lo, V hi, V lo: one tensor plane at a time (staging registers)
                 const bool isv = pl >= 2;
                 const _Float16* bp = base + ((pl & 1) ? qkv_lo : 0) + (isv ? 2 * H : H);
@@ -490,19 +491,19 @@ __global__ __launch_bounds__(512, 1) void attention_x3_stream_kernel(const _Floa
             for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { om[dt][r] *= alpha; ox[dt][r] *= alpha; }
-            // un-normalised probabilities (<= 1) as the split B operand; the 1 / l normalisation happens once at the end
-            f16x8 ph[NS], pl_[NS];
+            // un-normalised probabilities (<= 1) as the split B operand, built per 32-key step right before its MFMAs (building all
+            // NS pairs up front kept 32 more registers live and spilled 216 B per lane at D = 128: profiles/r03_xlsr2b_kernel_summary.txt);
+            // the 1 / l normalisation happens once at the end
 #pragma unroll
-            for (int ss = 0; ss < NS; ++ss)
+            for (int ss = 0; ss < NS; ++ss) {
+                f16x8 ph_, pl_s;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     _Float16 h0, l0, h1 = (_Float16)0.f, l1 = (_Float16)0.f;
                     split_f32_raw(s[2 * ss][r], h0, l0);
                     if (2 * ss + 1 < NTB) split_f32_raw(s[(2 * ss + 1 < NTB) ? 2 * ss + 1 : 0][r], h1, l1);
-                    ph[ss][r] = h0; pl_[ss][r] = l0; ph[ss][4 + r] = h1; pl_[ss][4 + r] = l1;
+                    ph_[r] = h0; pl_s[r] = l0; ph_[4 + r] = h1; pl_s[4 + r] = l1;
                 }
-#pragma unroll
-            for (int ss = 0; ss < NS; ++ss) {
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt) {
                     const int vo = (dt * 16 + fr) * VP + (((dt * 16 + fr) >> 3) & 7) * 8 + ss * 32 + g * 4;
@@ -511,9 +512,9 @@ __global__ __launch_bounds__(512, 1) void attention_x3_stream_kernel(const _Floa
                     const f16x4 b0 = *(const f16x4*)(Vt + D * VP + vo), b1 = two ? *(const f16x4*)(Vt + D * VP + vo + 16) : f16x4{0, 0, 0, 0};
                     const f16x8 vh = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
                     const f16x8 vl = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
-                    ox[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, pl_[ss], ox[dt], 0, 0, 0);
-                    om[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, ph[ss], om[dt], 0, 0, 0);
-                    ox[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl, ph[ss], ox[dt], 0, 0, 0);
+                    ox[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, pl_s, ox[dt], 0, 0, 0);
+                    om[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, ph_, om[dt], 0, 0, 0);
+                    ox[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl, ph_, ox[dt], 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
