@@ -397,6 +397,10 @@ int advh_attention_bwd_split(const void* qkv, int64_t qkv_lo, const void* dctx, 
                              int B, int T, int H, int heads, advh_stream_t stream);
 int advh_pool_logreg_bwd_split(const float* coef, const float* dlogit, float* dh, void* dh16, int64_t dh16_lo, int B, int T, int H,
                                advh_stream_t stream);
+/* fp32 -> split format on the device: dst[i] = hi, dst[dst_lo + i] = lo of src[i], i < n (csrc/device_math.h split_f32: saturates
+ * and raises the sticky range flag above 65 504).  The per-step weight refresh of the training path (train_addvisor.py:376-378
+ * steps the fp32 parameters with Adam; addvisor_hip/gemm.py GemmPlan.load_weights re-packs them).  src 16-byte aligned. */
+int advh_split_f32(const float* src, void* dst, int64_t dst_lo, int64_t n, advh_stream_t stream);
 /* dh [B][T][H] fp32 times GELU'(dact_src) (split pre-activation of the positional conv) -> split xg, rows [pad_left, pad_left+T) */
 int advh_posconv_gather_bwd_split(const float* dh, void* xg, int64_t xg_lo, int B, int T, int H, int G, int K, int pad_left,
                                   const void* dact_src, int64_t dact_lo, advh_stream_t stream);

@@ -305,3 +305,28 @@ def test_split_small_magnitudes(gpu_device):
     assert ref.abs().max() > 1e-6                                         # the result itself is not flushed
     torch.cuda.synchronize()
     _lib.check_overflow()
+
+
+def test_split_planes_device_matches_host(gpu_device):
+    """``split_planes`` of an fp32 tensor that already lives on the GPU (the training path's per-step weight refresh) is one
+    launch of ``advh_split_f32``; its planes are bit-identical to the host packer's (fp64 arithmetic on an fp32 source is exact),
+    including the |x| < 2^-14 rule, and an out-of-range value saturates and raises the sticky flag."""
+    _lib.init()
+    _lib.lib().advh_split_overflow(1)
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(37, 24, generator=g) * torch.logspace(-9, 4, 24)[None, :]        # 1e-9 .. 1e4 per column, 888 values
+    x[0, :4] = torch.tensor([0.0, -0.0, 2.0 ** -14, -(2.0 ** -14) * (1 - 2.0 ** -12)])
+    host = G.split_planes(x)
+    dev = G.split_planes(x.to(gpu_device))
+    torch.cuda.synchronize()
+    _lib.check_overflow()
+    assert dev.shape == host.shape and dev.dtype == torch.float16
+    assert torch.equal(dev.cpu().view(torch.int16), host.view(torch.int16))
+    odd = torch.randn(7, 3, generator=g)                                             # numel % 4 != 0: the host formulation
+    assert torch.equal(G.split_planes(odd.to(gpu_device)).cpu().view(torch.int16), G.split_planes(odd).view(torch.int16))
+    big = x.clone(); big[5, 5] = 1e5
+    s = G.split_planes(big.to(gpu_device))
+    torch.cuda.synchronize()
+    with pytest.raises(_lib.SplitRangeError):
+        _lib.check_overflow("test")
+    assert torch.isfinite(s.float()).all() and abs(float(G.join_planes(s.cpu())[5, 5]) - 65535.984) < 0.02

@@ -77,6 +77,7 @@ SIGNATURES = {
     "advh_bn_bwd_sums": (_i, [_p, _p, _i, _p, _p, _f, _p, _p, _p]),
     "advh_bn_bwd_apply": (_i, [_p, _p, _i, _p, _p, _p, _f, _p, _i64, _i64, _i64, _i64, _p]),
     "advh_transpose_gather": (_i, [_p, _p, _p, _p]),
+    "advh_split_f32": (_i, [_p, _p, _i64, _i64, _p]),
     "advh_unet_head_bwd": (_i, [_p, _p, _p, _f, _i64, _p, _p, _i, _p]),
     "advh_unet_head_wgrad": (_i, [_p, _p, _i64, _p, _p, _p]),
     "advh_unet_stem_wgrad": (_i, [_p, _i, _i, _i, _i, _i, _p, _i, _i, _p, _p, _p]),

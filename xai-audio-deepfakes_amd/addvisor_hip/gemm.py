@@ -124,6 +124,15 @@ def round_up(x: int, m: int) -> int:
 def split_planes(x: torch.Tensor) -> torch.Tensor:
     """Host-side packer of the split format (csrc/device_math.h): ``x`` (any float dtype) -> fp16 ``[2, *x.shape]`` with
     ``x = hi + lo * 2**-11``; computed in fp64, so an fp64 source (BatchNorm-folded / composed weights) keeps ~22 bits."""
+    if x.is_cuda and x.dtype == torch.float32 and x.numel() % 4 == 0:
+        # device tensors (the training path's per-step weight refresh): one HIP launch, no host synchronisation; out-of-range
+        # values saturate and raise the sticky flag (SplitRangeError at the next _lib.check) instead of the ValueError below
+        src = x.detach().contiguous()
+        out = torch.empty((2,) + tuple(src.shape), dtype=torch.float16, device=src.device)
+        if src.numel():
+            _lib.check(_lib.lib().advh_split_f32(src.data_ptr(), out.data_ptr(), src.numel(), src.numel(),
+                                                 torch.cuda.current_stream(src.device).cuda_stream), "advh_split_f32")
+        return out
     x64 = x.detach().to(torch.float64)
     # range of the format: |x| <= 65504 (hi is an fp16).  Weights / host tensors outside it are a caller error, reported here
     # rather than as saturated planes on the device (csrc/device_math.h split_f32 saturates and raises the sticky flag).

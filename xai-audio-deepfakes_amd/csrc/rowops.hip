@@ -191,6 +191,24 @@ __global__ __launch_bounds__(256) void pool_logreg_kernel(const float* __restric
     }
 }
 
+// fp32 -> split format on the device (the training path's per-step weight refresh: unet_train.py re-packs the live fp32
+// parameters; the torch formulation was a dozen fp64 element-wise launches and a host synchronisation per tensor).
+__global__ __launch_bounds__(256) void split_f32_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, long lo, long n) {
+    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    if (i + 4 <= n) {
+        const float4 t = *(const float4*)(src + i);
+        const float v[4] = {t.x, t.y, t.z, t.w};
+        store_h_rt<4>(dst, i, lo, v);
+    } else {
+        for (long j = i; j < n; ++j) {
+            _Float16 h, l;
+            split_f32(src[j], h, l);
+            dst[j] = h; dst[j + lo] = l;
+        }
+    }
+}
+
 }  // namespace advh
 
 using namespace advh;
@@ -276,3 +294,9 @@ extern "C" int advh_pool_logreg(const float* h, const float* coef, float interce
 }
 
 ADVH_SPLIT_FLAG_SETTER(advh_split_flag_rowops)
+
+extern "C" int advh_split_f32(const float* src, void* dst, int64_t dst_lo, int64_t n, advh_stream_t stream) {
+    if (!src || !dst || n <= 0 || dst_lo < n || dst_lo % 4 || ((uintptr_t)src & 15) || ((uintptr_t)dst & 7)) return ADVH_EINVAL;
+    hipLaunchKernelGGL(split_f32_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, src, (_Float16*)dst, (long)dst_lo, (long)n);
+    return ADVH_LAUNCH_CHECK();
+}

@@ -182,6 +182,7 @@ struct TrArgs {
     int sy, sx, ntap, oy[16], ox[16];
     long ld, col0;                        // dst row pitch (elements) and first column
     int rpt, r0;                          // dst row of (tap t, channel c) = t*rpt + r0 + c
+    int fuse;                             // all taps by one workgroup
 };
 
 __global__ __launch_bounds__(256) void transpose_gather_kernel(const _Float16* __restrict__ src, _Float16* __restrict__ dst, TrArgs a) {
@@ -190,9 +191,15 @@ __global__ __launch_bounds__(256) void transpose_gather_kernel(const _Float16* _
     __shared__ __attribute__((aligned(16))) _Float16 tile[64][72];
     const long M = (long)a.B * a.Hg * a.Wg;
     const long p0 = (long)blockIdx.x * 64;
-    const int t = blockIdx.y, cb = blockIdx.z * 64;             // tap, first channel of this 64-channel slab
+    const int cb = blockIdx.z * 64;                             // first channel of this 64-channel slab
     const int tid = threadIdx.x;
     const int nch = min(64, a.nC - cb);
+    // taps: one per workgroup (grid y), or -- a.fuse: unit stride, the taps of a layer differ by a few positions -- all of them in
+    // turn by ONE workgroup, so that taps 2.. re-read the slab from the CU's L1 instead of HBM (as separate workgroups they ran
+    // M / 64 workgroups apart: three HBM reads of the map; profiles/r03_train_f32_kernel_summary.txt)
+    const int t0 = a.fuse ? 0 : blockIdx.y, t1 = a.fuse ? a.ntap : t0 + 1;
+    for (int t = t0; t < t1; ++t) {
+    if (t > t0) __syncthreads();                                // the previous tap's scatter is done with the tile
     for (int i = tid; i < 64 * 8; i += 256) {                   // gather: 8 lanes read the 128 contiguous bytes of one position
         const int pl = i >> 3, ck = i & 7;
         f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -232,6 +239,7 @@ __global__ __launch_bounds__(256) void transpose_gather_kernel(const _Float16* _
         _Float16* d = dst + ((long)t * a.rpt + a.r0 + cb + c) * a.ld + a.col0 + col;
         if (col + 8 <= M) *(f16x8*)d = v;
         else for (int j = 0; j < 8 && col + j < M; ++j) d[j] = v[j];
+    }
     }
 }
 
@@ -479,7 +487,9 @@ extern "C" int advh_transpose_gather(const void* src, void* dst, const advh_tran
     a.ld = d->ld; a.col0 = d->col0; a.rpt = d->rpt; a.r0 = d->r0;
     const long M = (long)d->B * d->Hg * d->Wg;
     if (d->col0 + ((M + 7) / 8) * 8 > d->ld) return ADVH_EINVAL;
-    dim3 grid((unsigned)((M + 63) / 64), d->ntap, (d->nC + 63) / 64);
+    a.fuse = d->ntap > 1 && d->sx == 1 && d->sy == 1;
+    for (int t = 1; t < d->ntap; ++t) a.fuse = a.fuse && d->oy[t] == d->oy[0] && abs(d->ox[t] - d->ox[0]) <= 8;
+    dim3 grid((unsigned)((M + 63) / 64), a.fuse ? 1 : d->ntap, (d->nC + 63) / 64);
     hipLaunchKernelGGL(transpose_gather_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const _Float16*)src, (_Float16*)dst, a);
     return ADVH_LAUNCH_CHECK();
 }
