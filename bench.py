@@ -24,8 +24,9 @@ workload on this host's cores (rank 0, N = 1 only).  The default N = 1 invocatio
 (`"hifigan"`: HiFi-GAN V1, 256 x 251 mel frames), config 5's per-GPU share (`"ig"`: IntegratedGradients, 50 steps x
 16 clips, wav2vec2-large, fp32-class gradient chain; the fp16 chain under its `"f16"` sub-key), the vocoder variant of the step (`"explain_vocoder"`) and one rank's data-set loop of config 4
 through the drop-in `LMAC_metrics.run_addvisor_metrics` itself (`"dataset"`: 8 905 clips from an in-memory Dataset in pinned host memory,
-DataLoader + per-item upload + collate inside the timed region, ragged last batch) and
-appends them as extra keys; `--workload hifigan|ig|dataset` runs one of them as the headline.
+DataLoader + per-item upload + collate inside the timed region, ragged last batch) and SURVEY 8(f)'s training step (`"train"`: batch 64,
+U-Net forward / backward + LMAC-loss forward / backward + Adam through the drop-in modules, fp32-class chain; fp16 under `"f16"`) and
+appends them as extra keys; `--workload hifigan|ig|dataset|xlsr2b|train` runs one of them as the headline.
 """
 import argparse
 import json
@@ -55,7 +56,7 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=BATCH)
-    ap.add_argument("--workload", choices=("explain", "hifigan", "ig", "dataset", "xlsr2b"), default="explain")
+    ap.add_argument("--workload", choices=("explain", "hifigan", "ig", "dataset", "xlsr2b", "train"), default="explain")
     ap.add_argument("--precision", choices=("f32", "f16"), default="f32", help="headline precision of the explain workload")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (f16 / hifigan / ig keys)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -147,6 +148,12 @@ def main():
                 "unit": "explanations/s", "n_gpus": world, "steps": r["steps"], "warmup": 1, "ms_per_step": r["ms_per_step"], "higher_is_better": True,
                 "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic", "config": {"workload": r["workload"]},
                 "lmac": r["lmac"], "roofline": r["roofline"], "pipeline_tflops": r["pipeline_tflops"], "cpu_baseline": None}
+    elif args.workload == "train":
+        r = bench_train(ctx, args.precision, args.batch)
+        line = {"metric": "mask-decoder training clips/sec (4 s clips, wav2vec2-base frozen)", "value": round(r["value"] * world, 1), "unit": "clips/s",
+                "n_gpus": world, "steps": r["steps"], "warmup": 2, "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": r["dtype"], "data": "synthetic", "config": {"workload": r["workload"]}, "f16": r.get("f16"),
+                "cpu_baseline": None}
     elif args.workload == "dataset":
         r = bench_dataset(ctx, args.precision)
         line = {"metric": "explanations/sec over a host-resident data set (PCIe upload included)", "value": r["value"], "unit": "explanations/s",
@@ -392,6 +399,7 @@ def explain_line(ctx):
         line["dataset"] = bench_dataset(ctx, args.precision)
         line["hifigan"] = bench_hifigan(ctx, 256, 5, 1)
         line["ig"] = bench_ig(ctx, 16, 64)
+        line["train"] = bench_train(ctx, args.precision)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cfg = head["cfg"]
         emb_sd, coef, icpt, unet_sd = head["weights"]
@@ -582,6 +590,67 @@ def bench_ig(ctx, B, chunk, precision="f32", both=True):
     if both and precision == "f32":
         r = bench_ig(ctx, B, chunk, "f16", both=False)
         out["f16"] = {k: r[k] for k in ("value", "unit", "seconds", "approx_tflops_fwd_plus_dgrad", "finite", "roofline")}
+    return out
+
+
+def bench_train(ctx, precision="f32", B=64, steps=5, warmup=2, both=True):
+    """one step of the mask-decoder training loop (train_addvisor.py:364-381) through the drop-in modules -- U-Net
+    forward / backward on the HIP training kernels, LMAC loss forward and backward (masked ISTFT x2, frozen wav2vec2-base x2 with saves,
+    their input-gradient chain, ISTFT adjoint x2), two Adam steps -- at the path's precision; the fp16-operand chain under "f16"."""
+    import torch
+    from addvisor_hip import runtime as rt, synthetic as syn
+    saved = {k: os.environ.get(k) for k in ("ADDVISOR_PRECISION", "ADDVISOR_EMBEDDER", "ADDVISOR_AUDIO_LENGTH")}
+    os.environ.update(ADDVISOR_PRECISION=precision, ADDVISOR_EMBEDDER="base", ADDVISOR_AUDIO_LENGTH=str(AUDIO_LENGTH))
+    rt.reset()
+    try:
+        import addvisor, loss_function
+        dev = ctx["dev"]
+        ap = loss_function.audio_processor
+        ap.audio_length = AUDIO_LENGTH
+        w = syn.make_clips(B, AUDIO_LENGTH * 16000, seed=3).to(dev)
+        _, mag, ph = ap.compute_stft(w)
+        _, p = ap.classify(w)
+        T4 = 4 * (mag.shape[2] // 4)
+        x = mag[:, :512, :T4].unsqueeze(1).contiguous()
+        net = addvisor.UNet().to(dev)
+        net.train()
+        loss = loss_function.LMACLoss().to(dev)
+        opt_m, opt_w = torch.optim.Adam(net.parameters(), lr=3e-5), torch.optim.Adam(loss.parameters(), lr=1e-4)
+        vals = []
+
+        def step():
+            with torch.enable_grad():
+                total, _, _ = loss.loss_function(net(x).float(), mag, ph, p)
+                opt_m.zero_grad(); opt_w.zero_grad()
+                total.backward()
+            opt_m.step(); opt_w.step()
+            return total
+
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            vals.append(step())
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        vals = [float(v) for v in vals]
+        out = {"workload": f"mask-decoder training step (train_addvisor.py:364-381): batch {B} x {AUDIO_LENGTH} s, U-Net forward / backward + LMAC loss "
+                           "forward / backward through the frozen wav2vec2-base + two Adam steps, one GPU", "value": round(B / dt, 1), "unit": "clips/s",
+               "ms_per_step": round(1e3 * dt, 2), "steps": steps, "dtype": precision, "finite": all(v == v and abs(v) != float("inf") for v in vals),
+               "loss_first_last": [round(vals[0], 5), round(vals[-1], 5)]}
+        del net, loss, opt_m, opt_w, x, mag, ph, w
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        rt.reset()
+        torch.cuda.empty_cache()
+    if both and precision == "f32":
+        r = bench_train(ctx, "f16", B, steps, warmup, both=False)
+        out["f16"] = {k: r[k] for k in ("value", "unit", "ms_per_step", "finite", "loss_first_last")}
     return out
 
 
