@@ -141,7 +141,7 @@ def main():
     if args.workload == "hifigan":
         line = hifigan_line(ctx, bench_hifigan(ctx, args.batch if args.batch != BATCH else 256, args.steps, args.warmup))
     elif args.workload == "ig":
-        line = ig_line(ctx, bench_ig(ctx, 16, 64, args.precision))
+        line = ig_line(ctx, bench_ig(ctx, 16, 160, args.precision))
     elif args.workload == "xlsr2b":
         r = bench_xlsr2b(ctx, args.precision, args.steps if args.steps != 10 else 3, min(args.warmup, 1) or 1)
         line = {"metric": "explanations/sec (16 kHz, 4 s clips), XLS-R-2B-width embedder", "value": r["value"],
@@ -398,7 +398,7 @@ def explain_line(ctx):
         line["xlsr2b"] = bench_xlsr2b(ctx, args.precision)
         line["dataset"] = bench_dataset(ctx, args.precision)
         line["hifigan"] = bench_hifigan(ctx, 256, 5, 1)
-        line["ig"] = bench_ig(ctx, 16, 64)
+        line["ig"] = bench_ig(ctx, 16, 160)
         line["train"] = bench_train(ctx, args.precision)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cfg = head["cfg"]
@@ -560,7 +560,9 @@ def bench_ig(ctx, B, chunk, precision="f32", both=True):
     """IntegratedGradients, n_steps = 50, wav2vec2-large, B clips = one GPU's share of config 5's batch of 128 over 8 GPUs;
     path-batched forward + dgrad-only backward.  Headline precision: the fp32-class chain (split-format activations and
     gradients, three fp16 MFMAs per product, attention backward on the fp32 MFMA -- the reference differentiates with fp32
-    autograd, captum_saliency.py:131-135); the fp16-operand chain is timed too and reported under "f16"."""
+    autograd, captum_saliency.py:131-135); the fp16-operand chain is timed too and reported under "f16".
+    `chunk` = Captum's internal_batch_size (the reference leaves it unset): 160 = ten whole steps per chunk, five equal chunks; 64 pads the
+    50 steps to 13 chunks of 4 (1 496 against 1 632 path points/s, profiles/r03_ig_internal_batch.txt)."""
     import torch
     from addvisor_hip import gemm as G, synthetic as syn
     from addvisor_hip.attribution import HipAttribution
