@@ -305,12 +305,16 @@ static int launch_att_bwd_f32(const void* qkv, long qkv_lo, const void* dctx, lo
 
 using namespace advh;
 
+int g_att_bwd_force_f32 = 0;
+
 extern "C" int advh_attention_bwd_split(const void* qkv, int64_t qkv_lo, const void* dctx, int64_t dctx_lo, void* dqkv, int64_t dqkv_lo,
                                         int B, int T, int H, int heads, advh_stream_t stream) {
     if (!qkv || !dctx || !dqkv || B <= 0 || T <= 0 || heads <= 0 || H % heads) return ADVH_EINVAL;
     if (qkv_lo <= 0 || dctx_lo <= 0 || dqkv_lo <= 0 || qkv_lo % 8 || dctx_lo % 8 || dqkv_lo % 8) return ADVH_EINVAL;
     const int dm = H / heads;
     if (T > 256 || dm % 8 || dm > 128) return ADVH_EUNSUPPORTED;
+    if (dm <= 64 && !g_att_bwd_force_f32)           // three fp16 MFMAs per product instead of eight fp32 MFMAs (attention_bwd_x3.hip)
+        return advh_attention_bwd_x3_launch(qkv, qkv_lo, dctx, dctx_lo, dqkv, dqkv_lo, B, T, H, heads, (hipStream_t)stream);
     const int D = dm <= 32 ? 32 : (dm <= 64 ? 64 : 128);
     const float scale = 1.f / sqrtf((float)dm);
     hipStream_t s = (hipStream_t)stream;

@@ -9,6 +9,7 @@ int advh_init_attention();   // attention.hip
 // per-translation-unit setters of the split-format range flag pointer (csrc/device_math.h: ADVH_SPLIT_FLAG_SETTER)
 int advh_split_flag_attention(int* flag);
 int advh_split_flag_attention_bwd_f32(int* flag);
+int advh_split_flag_attention_bwd_x3(int* flag);
 int advh_split_flag_backward(int* flag);
 int advh_split_flag_frontend(int* flag);
 int advh_split_flag_frontend_bwd(int* flag);
@@ -18,6 +19,12 @@ int advh_split_flag_rowops(int* flag);
 int advh_split_flag_unet_misc(int* flag);
 int advh_split_flag_unet_train(int* flag);
 int advh_split_flag_resblock_pair_x3(int* flag);
+
+// attention backward of the fp32-class mode: the split-arithmetic kernel for head dims <= 64 (attention_bwd_x3.hip), called by
+// advh_attention_bwd_split (attention_bwd_f32.hip) after it validated the arguments; g_att_bwd_force_f32: advh_set_option("attention_bwd_mfma_f32")
+int advh_attention_bwd_x3_launch(const void* qkv, long qkv_lo, const void* dctx, long dctx_lo, void* dqkv, long dqkv_lo, int B, int T, int H,
+                                 int heads, hipStream_t s);
+extern int g_att_bwd_force_f32;
 
 // Raise a kernel's dynamic-LDS limit to `bytes` once per (kernel, DEVICE): the attribute belongs to the device's copy of
 // the code object, and one process may drive several GPUs (a per-process "done" flag left the second device at 64 KiB).

@@ -470,6 +470,10 @@ extern "C" int advh_set_option(const char* name, int value) {
         g_stft_fb = value;
         return ADVH_OK;
     }
+    if (!strcmp(name, "attention_bwd_mfma_f32")) {          // 1: head dims <= 64 on the fp32 matrix instruction too (the pre-x3 kernel; A/B runs)
+        g_att_bwd_force_f32 = value != 0;
+        return ADVH_OK;
+    }
     return ADVH_EINVAL;
 }
 
@@ -504,7 +508,7 @@ extern "C" int advh_init(void) {
     }
     int* dflag = nullptr;
     if (hipHostGetDevicePointer((void**)&dflag, g_split_flag_host, 0) != hipSuccess) return ADVH_ELAUNCH;
-    int (*const setters[])(int*) = {advh_split_flag_attention, advh_split_flag_attention_bwd_f32, advh_split_flag_backward, advh_split_flag_frontend, advh_split_flag_frontend_bwd, advh_split_flag_gemm, advh_split_flag_hifigan, advh_split_flag_rowops, advh_split_flag_unet_misc, advh_split_flag_unet_train, advh_split_flag_resblock_pair_x3};
+    int (*const setters[])(int*) = {advh_split_flag_attention, advh_split_flag_attention_bwd_f32, advh_split_flag_attention_bwd_x3, advh_split_flag_backward, advh_split_flag_frontend, advh_split_flag_frontend_bwd, advh_split_flag_gemm, advh_split_flag_hifigan, advh_split_flag_rowops, advh_split_flag_unet_misc, advh_split_flag_unet_train, advh_split_flag_resblock_pair_x3};
     for (auto set : setters)
         if ((rc = set(dflag)) != ADVH_OK) return rc;
     g_init_done[dev] = true;
