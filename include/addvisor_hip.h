@@ -44,7 +44,9 @@ const char* advh_version(void);
 int advh_init(void);
 
 /* Tuning knobs (process-wide, not thread-safe; set before launching work):
- *   "stft_frames_per_workgroup" = 8 (default) | 16 : STFT / ISTFT frames per workgroup. */
+ *   "stft_frames_per_workgroup" = 8 (default) | 16 : STFT / ISTFT frames per workgroup.
+ *   "attention_bwd_mfma_f32" = 0 (default) | 1 : advh_attention_bwd_split on the fp32-input matrix instruction for every
+ *       head dim (1) instead of the split-arithmetic kernel for head dims <= 64 (0); same results to 1e-6 (A/B runs). */
 int advh_set_option(const char* name, int value);
 
 /* ---------------------------------------------------------------------------------------------
@@ -388,7 +390,9 @@ int advh_unet_head_split(const void* y, int64_t y_lo, int B, int H, int W, int P
  * train_addvisor.py:376: loss.backward() through the frozen embedder).  Dense dgrad products are advh_gemm_f16 launches with
  * desc.split = 1 (transposed split weights, split gradients; dact_src / out_pre are plane pairs sharing o_lo); these are the
  * split-format forms of the row kernels above -- same arithmetic, fp16 tensors replaced by plane pairs -- and the attention
- * backward on the fp32-input matrix instruction (v_mfma_f32_16x16x4_f32; head dim a multiple of 8 up to 128, T <= 256).  */
+ * backward (head dim a multiple of 8 up to 128, T <= 256): head dims <= 64 in split arithmetic (three fp16 MFMAs per product,
+ * csrc/attention_bwd_x3.hip), larger ones on the fp32-input matrix instruction v_mfma_f32_16x16x4_f32 (csrc/attention_bwd_f32.hip;
+ * advh_set_option("attention_bwd_mfma_f32", 1) selects it for every head dim).  */
 int advh_layernorm_bwd_split(const void* x, int x_is_f32, int64_t x_lo, const void* dy, int dy_is_f32, int64_t dy_lo,
                              const float* gamma, const float* beta, int gelu_fwd, const float* add, const void* dact_src,
                              int64_t dact_lo, float* out_f, void* out_h, int64_t out_lo, int M, int C, float eps, int remap_T,

@@ -53,3 +53,11 @@ def test_attention_and_resblock_kernels_do_not_spill():
         assert hit, (src, sorted(res))
         for k, v in hit.items():
             assert v["scratch"] == 0, (k, v)
+    # the split-arithmetic attention backward: no scratch, except the 13-tile / head-dim-64 instance (T = 199: the production
+    # shape), which keeps <= 96 bytes per lane for values that live across its two passes -- outside the product loops; with the
+    # whole register file (four wavefronts) it measured 392 us against 293 us (profiles/r03_attention_bwd_x3.txt)
+    res = resources("attention_bwd_x3.hip")
+    hit = {k: v for k, v in res.items() if "attention_bwd_x3_kernel" in k}
+    assert len(hit) == 8, sorted(res)
+    for k, v in hit.items():
+        assert v["scratch"] <= (96 if "ILi13ELi64ELi8E" in k else 0), (k, v)

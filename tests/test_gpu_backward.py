@@ -100,10 +100,17 @@ def test_layernorm_bwd_split(gpu_device):
         assert relerr(G.join_planes(out_h.cpu()), out_f.cpu()) < 1e-6          # the split output carries the fp32 result to ~2^-22
 
 
-@pytest.mark.parametrize("T,heads,D", [(199, 3, 64), (50, 2, 32), (249, 2, 64), (199, 2, 120), (60, 1, 40), (256, 1, 128), (33, 2, 16)])
-def test_attention_bwd_split(gpu_device, T, heads, D):
-    """fp32-class attention backward (v_mfma_f32_16x16x4_f32 on split-format q | k | v and dctx) vs fp64 autograd."""
+@pytest.mark.parametrize("kernel", ["default", "mfma_f32"])
+@pytest.mark.parametrize("T,heads,D", [(199, 3, 64), (50, 2, 32), (249, 2, 64), (199, 2, 120), (60, 1, 40), (256, 1, 128), (33, 2, 16), (208, 1, 48),
+                                       (209, 2, 64), (128, 2, 64), (17, 1, 8)])
+def test_attention_bwd_split(gpu_device, T, heads, D, kernel):
+    """fp32-class attention backward on split-format q | k | v and dctx vs fp64 autograd: head dims <= 64 in split arithmetic
+    (attention_bwd_x3.hip: three fp16 MFMAs per product, transposing LDS reads; every tile-count instance incl. the 4-wavefront one
+    for T > 208), larger head dims -- and every head dim under ``attention_bwd_mfma_f32`` -- on v_mfma_f32_16x16x4_f32."""
     _lib.init()
+    if kernel == "mfma_f32" and D > 64:
+        pytest.skip("head dims > 64 run the fp32-MFMA kernel by default")
+    _lib.check(_lib.lib().advh_set_option(b"attention_bwd_mfma_f32", int(kernel == "mfma_f32")), "advh_set_option")
     g = torch.Generator().manual_seed(T + D)
     B, H = 2, heads * D
     qs = G.split_planes(torch.randn(B * T, 3 * H, generator=g) * 0.7)
@@ -120,6 +127,7 @@ def test_attention_bwd_split(gpu_device, T, heads, D):
     rc = _lib.lib().advh_attention_bwd_split(qd.data_ptr(), qd.stride(0), dd.data_ptr(), dd.stride(0), out.data_ptr(), out.stride(0),
                                              B, T, H, heads, torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
+    _lib.lib().advh_set_option(b"attention_bwd_mfma_f32", 0)
     assert rc == 0
     got = G.join_planes(out.cpu()).double()
     assert torch.isfinite(got).all()                                       # every element of dqkv is written

@@ -12,7 +12,7 @@ import csv, glob, collections
 per = collections.defaultdict(list)
 for fn in glob.glob("$OUT/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(fn)):
-        if "attention_bwd_f32" in r["Kernel_Name"]:
+        if "attention_bwd_" in r["Kernel_Name"]:
             per[r["Counter_Name"]].append(float(r["Counter_Value"]))
 for c, v in sorted(per.items()):
     print(f"    {c:28s} {sum(v)/len(v):16.0f}  (n={len(v)})")

@@ -57,14 +57,17 @@ __device__ __forceinline__ void stage_planes(_Float16* ph, _Float16* pl, const _
     }
 }
 
-// transposed fragment: lane (g, fr) receives column c0 + fr of rows r0 + 4 g .. + 3 and r0 + 16 + 4 g .. + 3 of an LDS plane
-template <int D>
-__device__ __forceinline__ f16x8 tr8(lds_cptr plane, int r0, int g, int fr, int c0) {
+// transposed fragment: lane (g, fr) receives column c0 + fr of rows r0 + 4 g .. + 3 and r0 + 16 + 4 g .. + 3 of an LDS plane.
+// r0 is a multiple of 32, so the swizzle term of a row depends on the lane only: tr_off<D>(g, fr, c0) is the lane's byte offset of the
+// first read within a 32-row step (computed once per wavefront and column group), the second read sits 16 rows further.
+template <int D> __device__ __forceinline__ int tr_off(int g, int fr, int c0) {
     const int q = fr >> 2, p = fr & 3;
-    const int ra = r0 + 4 * g + q, rb = ra + 16;
-    const int ch = (c0 >> 3) + (p >> 1), sub = (p & 1) * 8;
-    const auto* pa = (const __attribute__((address_space(3))) trvec*)(plane + 2 * swz<D>(ra, ch) + sub);
-    const auto* pb = (const __attribute__((address_space(3))) trvec*)(plane + 2 * swz<D>(rb, ch) + sub);
+    return 2 * swz<D>(4 * g + q, (c0 >> 3) + (p >> 1)) + (p & 1) * 8;
+}
+template <int D>
+__device__ __forceinline__ f16x8 tr8(lds_cptr plane, int off) {
+    const auto* pa = (const __attribute__((address_space(3))) trvec*)(plane + off);
+    const auto* pb = (const __attribute__((address_space(3))) trvec*)(plane + off + 16 * (2 * D));
     trvec lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) trvec*)pa);
     trvec hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) trvec*)pb);
     f16x8 r;
@@ -110,7 +113,13 @@ __global__ __launch_bounds__(64 * NW) void attention_bwd_x3_kernel(const _Float1
     _Float16* dbase = dqkv + (long)b * T * ld + head * dm;
     const float c2 = scale * LOG2E_X3;
     const int nst = (T + 31) / 32;                                       // 32-row steps that hold any row < T
+    int troff[DG], rowoff[KK];                                           // per-lane LDS offsets (bytes / halfs) within a 32-row step / 16-row tile
+#pragma unroll
+    for (int dt = 0; dt < DG; ++dt) troff[dt] = tr_off<D>(g, fr, 16 * dt);
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) rowoff[kk] = swz<D>(fr, kk * 4 + g);
 
+    for (int i = tid; i < 3 * ROWS; i += 64 * NW) rmax[i] = 0.f;          // rows past the last query tile: finite statistics (pass B selects them away)
     stage_planes<ROWS, D, 64 * NW>(P0h, P0l, base + H, qkv_lo, ld, T, dm, tid);
     stage_planes<ROWS, D, 64 * NW>(P1h, P1l, base + 2 * H, qkv_lo, ld, T, dm, tid);
     __syncthreads();
@@ -132,10 +141,9 @@ __global__ __launch_bounds__(64 * NW) void attention_bwd_x3_kernel(const _Float1
 #pragma unroll
             for (int kt = 0; kt < NT; ++kt) {
                 f32x4 sm_ = {0.f, 0.f, 0.f, 0.f}, sx = sm_;
-                const int key = kt * 16 + fr;
 #pragma unroll
                 for (int kk = 0; kk < KK; ++kk) {
-                    const int o = swz<D>(key, kk * 4 + g);
+                    const int o = kt * 16 * D + rowoff[kk];
                     const f16x8 kh = *(const f16x8*)(P0h + o), kl = *(const f16x8*)(P0l + o);
                     MFMA_X3(sm_, sx, kh, kl, qh[kk], ql[kk]);          // S^T  [key][q]
                 }
@@ -155,10 +163,9 @@ __global__ __launch_bounds__(64 * NW) void attention_bwd_x3_kernel(const _Float1
 #pragma unroll
             for (int kt = 0; kt < NT; ++kt) {
                 f32x4 pm = {0.f, 0.f, 0.f, 0.f}, px = pm;
-                const int key = kt * 16 + fr;
 #pragma unroll
                 for (int kk = 0; kk < KK; ++kk) {
-                    const int o = swz<D>(key, kk * 4 + g);
+                    const int o = kt * 16 * D + rowoff[kk];
                     const f16x8 vh = *(const f16x8*)(P1h + o), vl = *(const f16x8*)(P1l + o);
                     MFMA_X3(pm, px, vh, vl, oh[kk], ol[kk]);           // dP^T [key][q]
                 }
@@ -182,7 +189,7 @@ __global__ __launch_bounds__(64 * NW) void attention_bwd_x3_kernel(const _Float1
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { const float e = exp2f(s[kt][r] - mx); s[kt][r] = e; sum += e; }
+            for (int r = 0; r < 4; ++r) { const float e = __builtin_amdgcn_exp2f(s[kt][r] - mx); s[kt][r] = e; sum += e; }
         sum += __shfl_xor(sum, 16, 64);
         sum += __shfl_xor(sum, 32, 64);
         const float inv = 1.f / sum;
@@ -210,7 +217,7 @@ __global__ __launch_bounds__(64 * NW) void attention_bwd_x3_kernel(const _Float1
             split_f32_vec<8>(v, bh, bl);
 #pragma unroll
             for (int dt = 0; dt < DG; ++dt) {
-                const f16x8 ah = tr8<D>(L0h, 32 * ss, g, fr, 16 * dt), al = tr8<D>(L0l, 32 * ss, g, fr, 16 * dt);
+                const f16x8 ah = tr8<D>(L0h, 32 * ss * (2 * D) + troff[dt]), al = tr8<D>(L0l, 32 * ss * (2 * D) + troff[dt]);
                 MFMA_X3(om[dt], ox[dt], ah, al, bh, bl);           // dQ^T [d][q] += K^T dS^T
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -249,28 +256,28 @@ __global__ __launch_bounds__(64 * NW) void attention_bwd_x3_kernel(const _Float1
         for (int dt = 0; dt < DG; ++dt) { dkm[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dkx[dt] = dkm[dt]; dvm[dt] = dkm[dt]; dvx[dt] = dkm[dt]; }
         for (int ss = 0; ss < nst; ++ss) {
             float p[8], ds[8];
+            const int sb = ss * 32 * D;                                       // first element of the step's rows in a plane
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const int qrow = ss * 32 + h * 16 + fr;                       // < ROWS; rows >= T are zero in LDS
                 f32x4 sm_ = {0.f, 0.f, 0.f, 0.f}, sx = sm_, pm = sm_, px = sm_;
 #pragma unroll
                 for (int kk = 0; kk < KK; ++kk) {
-                    const int o = swz<D>(qrow, kk * 4 + g);
+                    const int o = sb + h * 16 * D + rowoff[kk];             // rows >= T are zero in LDS
                     const f16x8 qah = *(const f16x8*)(P0h + o), qal = *(const f16x8*)(P0l + o);
                     const f16x8 oah = *(const f16x8*)(P1h + o), oal = *(const f16x8*)(P1l + o);
                     MFMA_X3(sm_, sx, qah, qal, kh[kk], kl[kk]);     // S  [q][key]
                     MFMA_X3(pm, px, oah, oal, vh[kk], vl[kk]);      // dP [q][key]
                 }
+                const int q0 = ss * 32 + h * 16 + g * 4;            // this lane's four query rows; its key column = krow
+                const float4 mx4 = *(const float4*)(rmax + q0), iv4 = *(const float4*)(rinv + q0), dl4 = *(const float4*)(rdel + q0);
+                const float mxs[4] = {mx4.x, mx4.y, mx4.z, mx4.w}, ivs[4] = {iv4.x, iv4.y, iv4.z, iv4.w}, dls[4] = {dl4.x, dl4.y, dl4.z, dl4.w};
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int q = ss * 32 + h * 16 + g * 4 + r;     // this lane's query rows; its key column = krow
-                    float pv = 0.f, dv = 0.f;
-                    if (q < T && krow < T) {
-                        pv = exp2f(fmaf(sx[r], SPLIT_LO_INV, sm_[r]) * c2 - rmax[q]) * rinv[q];
-                        dv = pv * (fmaf(px[r], SPLIT_LO_INV, pm[r]) - rdel[q]) * scale;
-                    }
-                    p[4 * h + r] = pv;
-                    ds[4 * h + r] = dv;
+                for (int r = 0; r < 4; ++r) {                       // branch-free: statistics of rows >= T are finite (initialised), selected away
+                    const float pv = __builtin_amdgcn_exp2f(fmaf(sx[r], SPLIT_LO_INV, sm_[r]) * c2 - mxs[r]) * ivs[r];   // v_exp_f32: argument <= ~0, tiny results may flush
+                    const float dv = pv * (fmaf(px[r], SPLIT_LO_INV, pm[r]) - dls[r]) * scale;
+                    const bool ok = q0 + r < T && krow < T;
+                    p[4 * h + r] = ok ? pv : 0.f;
+                    ds[4 * h + r] = ok ? dv : 0.f;
                 }
             }
             f16x8 ph, pl, dh, dl;
@@ -279,8 +286,9 @@ __global__ __launch_bounds__(64 * NW) void attention_bwd_x3_kernel(const _Float1
             split_f32_vec<8>(ds, dh, dl);
 #pragma unroll
             for (int dt = 0; dt < DG; ++dt) {
-                const f16x8 qth = tr8<D>(L0h, 32 * ss, g, fr, 16 * dt), qtl = tr8<D>(L0l, 32 * ss, g, fr, 16 * dt);
-                const f16x8 oth = tr8<D>(L1h, 32 * ss, g, fr, 16 * dt), otl = tr8<D>(L1l, 32 * ss, g, fr, 16 * dt);
+                const int a = 2 * sb + troff[dt];                   // one per-lane address per column group; planes and the +16 rows are immediates
+                const f16x8 qth = tr8<D>(L0h, a), qtl = tr8<D>(L0l, a);
+                const f16x8 oth = tr8<D>(L1h, a), otl = tr8<D>(L1l, a);
                 MFMA_X3(dkm[dt], dkx[dt], qth, qtl, dh, dl);        // dK^T [d][key] += Q^T dS
                 MFMA_X3(dvm[dt], dvx[dt], oth, otl, ph, pl);        // dV^T [d][key] += dO^T P
             }
@@ -299,12 +307,11 @@ __global__ __launch_bounds__(64 * NW) void attention_bwd_x3_kernel(const _Float1
     }
 }
 
-template <int NT, int D>
+template <int NT, int D, int NW>
 static int launch_att_bwd_x3(const void* qkv, long qkv_lo, const void* dctx, long dctx_lo, void* dqkv, long dqkv_lo, int B, int T, int H,
                              int heads, int dm, float scale, hipStream_t s) {
     constexpr int lds = AttBwdX3<NT, D>::LDS_BYTES;
     static_assert(lds <= 160 * 1024, "two matrices in two planes must fit");
-    constexpr int NW = 8;
     if (advh_ensure_lds((const void*)attention_bwd_x3_kernel<NT, D, NW>) != ADVH_OK) return ADVH_ELAUNCH;
     hipLaunchKernelGGL((attention_bwd_x3_kernel<NT, D, NW>), dim3(heads, B), dim3(64 * NW), lds, s, (const _Float16*)qkv, qkv_lo,
                        (const _Float16*)dctx, dctx_lo, (_Float16*)dqkv, dqkv_lo, T, H, dm, scale);
@@ -322,10 +329,14 @@ int advh_attention_bwd_x3_launch(const void* qkv, long qkv_lo, const void* dctx,
     const int D = dm <= 32 ? 32 : 64;
     const float scale = 1.f / sqrtf((float)dm);
     const int nt = (T + 15) / 16;
-#define ATX(NT_, D_) return launch_att_bwd_x3<NT_, D_>(qkv, qkv_lo, dctx, dctx_lo, dqkv, dqkv_lo, B, T, H, heads, dm, scale, s)
+#define ATX(NT_, D_, NW_) return launch_att_bwd_x3<NT_, D_, NW_>(qkv, qkv_lo, dctx, dctx_lo, dqkv, dqkv_lo, B, T, H, heads, dm, scale, s)
+    // eight wavefronts (two per SIMD, 256 VGPRs each: the 13-tile / head-dim-64 instance keeps 68 bytes per lane of scratch for values
+    // that live across the passes, outside the product loops, and still beats four wavefronts 293 to 392 us); 16 key tiles x head dim 64
+    // need 2 x 16 score registers per lane in pass A: four wavefronts with the whole register file (356 us at 64 x 12 x 249) instead of
+    // 352 bytes of scratch (372 us).  profiles/r03_attention_bwd_x3.txt
 #define ATX_D(D_)                                                                     \
     do {                                                                              \
-        if (nt <= 4) ATX(4, D_); else if (nt <= 8) ATX(8, D_); else if (nt <= 13) ATX(13, D_); else ATX(16, D_); \
+        if (nt <= 4) ATX(4, D_, 8); else if (nt <= 8) ATX(8, D_, 8); else if (nt <= 13) ATX(13, D_, 8); else ATX(16, D_, 4); \
     } while (0)
     if (D == 32) ATX_D(32);
     else ATX_D(64);
