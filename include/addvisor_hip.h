@@ -592,6 +592,10 @@ typedef struct advh_wgrad2d_desc {
 } advh_wgrad2d_desc;
 int advh_conv_wgrad2d_parts(int C, int B, int H, int W);
 int advh_conv_wgrad2d_f16(const advh_wgrad2d_desc* d, int C, float* dw, advh_stream_t stream);
+/* The same weight gradient in the fp32-class mode: X and DZ are split-format maps (lo plane x_lo / dz_lo elements behind the hi plane),
+ * three MFMAs per fragment pair (the arithmetic of the x3 GEMM), fp32 partials and the same fixed-order reduction.  Replaces four operand
+ * transposes + a split-K GEMM per layer (train_addvisor.py:376 loss.backward() through addvisor.py:20-24).  */
+int advh_conv_wgrad2d_split(const advh_wgrad2d_desc* d, int C, int64_t x_lo, int64_t dz_lo, float* dw, advh_stream_t stream);
 
 /* One fused HiFi-GAN ResBlock1 step for the 32- / 64-channel stages (speechbrain HifiganGenerator via hifigan.py:106-110,
  * 180): out = x + conv2(lrelu(conv1(lrelu(x)))) on a zero-haloed channels-last fp16 map [M][C] (rows m with

@@ -39,7 +39,7 @@ from . import _lib, gemm as G
 from .embedder import default_precision
 
 SLOPE = 0.2
-WGRAD_TILES = True   # 3x3 square 32/64-channel layers: wgrad on the LDS-tile kernel (ds_read_b64_tr_b16) instead of transposes + split-K GEMM
+WGRAD_TILES = True   # 3x3 square 32/64-channel layers: wgrad on the LDS-tile kernel (ds_read_b64_tr_b16; fp16 and split-arithmetic forms) instead of transposes + split-K GEMM
 G32 = False       # keep the activation gradients a BatchNorm backward consumes in fp32 (measured: no accuracy difference, +30 % BN traffic)
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
@@ -255,7 +255,7 @@ class HipUNetTrain:
         L["Cin"] = Cin
         # ---- wgrad, 3x3 stride-1 square 32 / 64-channel layers: LDS-tile kernel with transposing operand reads, no copies
         f0 = m[srcs[0]]
-        if (WGRAD_TILES and not sp and len(srcs) == 1 and k == (3, 3) and stride == (1, 1) and dil == (1, 1) and Cin == Cout and Cout in (32, 64)
+        if (WGRAD_TILES and len(srcs) == 1 and k == (3, 3) and stride == (1, 1) and dil == (1, 1) and Cin == Cout and Cout in (32, 64)
                 and f0.PH >= 1 and f0.PW >= 1):
             nparts = _lib.lib().advh_conv_wgrad2d_parts(Cout, B, Hd, Wd)
             L["wg2d"] = Wgrad2dDesc(B=B, H=Hd, W_=Wd, PHx=f0.PH, PWx=f0.PW, PHz=pph, PWz=ppw)
@@ -479,7 +479,11 @@ class HipUNetTrain:
                 d2.X, d2.DZ, d2.partial = m[L["srcs"][0]].t.data_ptr(), dzm.t.data_ptr(), L["wg2d_part"].data_ptr()
                 Cn = z[dst].C
                 dw9 = torch.empty(9, Cn, Cn, dtype=torch.float32, device=self.dev)
-                _lib.check(lib.advh_conv_wgrad2d_f16(C.byref(d2), Cn, dw9.data_ptr(), st), "advh_conv_wgrad2d_f16")
+                if self.split:
+                    xm = m[L["srcs"][0]].t
+                    _lib.check(lib.advh_conv_wgrad2d_split(C.byref(d2), Cn, xm.stride(0), dzm.t.stride(0), dw9.data_ptr(), st), "advh_conv_wgrad2d_split")
+                else:
+                    _lib.check(lib.advh_conv_wgrad2d_f16(C.byref(d2), Cn, dw9.data_ptr(), st), "advh_conv_wgrad2d_f16")
                 grads[L["cname"] + ".weight"] = (dw9.view(3, 3, Cn, Cn).permute(2, 3, 0, 1) / S).contiguous()
             else:
                 self._wgrad_gemm(L, m, z, dzm, dst, w, grads, S)

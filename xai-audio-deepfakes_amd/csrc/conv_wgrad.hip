@@ -130,6 +130,112 @@ __global__ __launch_bounds__(256) void conv_wgrad2d_kernel(const advh_wgrad2d_de
     }
 }
 
+// fp32-class form (round 3): both maps are split-format plane pairs (hi plane, lo plane x_lo / z_lo elements behind), every fragment pair
+// costs three MFMAs (acc += Zh Xh; accx += Zh Xl + Zl Xh; result acc + accx * 2^-11, the arithmetic of gemm_x3_kernel), and the two planes of a
+// tile are staged by the same LDS DMA.  The split-K GEMM it replaces for these layers needed four operand transposes per layer (both planes of
+// x with its three horizontal taps and of dz: 2.2 ms for the 512 x 196 x 32-channel map of a 64-clip batch) and then ran at 58 TFLOP/s because
+// its A operand is re-read once per vertical tap (profiles/r03_train_f32_kernel_summary.txt).  C = 32: 16 x 16-position tiles, one buffer
+// (74 KiB), two workgroups per CU hide each other's loads; C = 64: 320 accumulator registers => one wavefront per SIMD, 8 x 16-position tiles
+// in a two-slot ring (156 KiB) so that the next tile's DMA runs under the MFMAs.
+template <int C, int TR, int NBUF>
+__global__ __launch_bounds__(256) void conv_wgrad2d_x3_kernel(const advh_wgrad2d_desc p, long x_lo, long z_lo) {
+    constexpr int CH = C / 8, CT = C / 16, CIG = CT / 2, PR = 18, SRX = (TR + 2) * PR, SRZ = TR * 16, MAXU = 5;
+    constexpr int NX = (SRX * CH + 63) & ~63, NZ = SRZ * CH;      // 16-byte chunks per plane and buffer
+    constexpr int PLN = (NX + NZ) * 16, BUF = 2 * PLN;            // bytes of one plane / of one buffer (hi plane, lo plane)
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3, fr = lane & 15;
+    const _Float16* X = (const _Float16*)p.X;
+    const _Float16* Z = (const _Float16*)p.DZ;
+    const int Hx = p.H + 2 * p.PHx, Wx = p.W_ + 2 * p.PWx, Hz = p.H + 2 * p.PHz, Wz = p.W_ + 2 * p.PWz;
+    const int tx = (p.W_ + 15) / 16, ty = (p.H + TR - 1) / TR, ntiles = p.B * ty * tx;
+    auto load_tile = [&](int tile, int buf) {
+        const int x0 = (tile % tx) * 16, r_ = tile / tx, y0 = (r_ % ty) * TR, b = r_ / ty;
+        char* xd = lds + (size_t)buf * BUF;
+        char* zd = xd + (size_t)NX * 16;
+        for (int i = tid; i < NX; i += 256) {                      // (TR + 2) x 18 input patch; rows outside the map are clamped (finite)
+            int row = i / CH, pos = i % CH;
+            if (row >= SRX) row = 0;
+            int gy = min(y0 + p.PHx - 1 + row / PR, Hx - 1), gx = min(x0 + p.PWx - 1 + row % PR, Wx - 1);
+            const _Float16* src = X + (((long)b * Hx + gy) * Wx + gx) * C + ((pos ^ wswz<C>(i / CH)) * 8);
+            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src), LDS_PTR(xd + (size_t)(i - lane) * 16), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src + x_lo), LDS_PTR(xd + PLN + (size_t)(i - lane) * 16), 16, 0, 0);
+        }
+        for (int i = tid; i < NZ; i += 256) {                      // TR x 16 dz tile; positions outside the image read a halo zero
+            const int row = i / CH, pos = i % CH;
+            const int ly = row >> 4, lx = row & 15;
+            const bool in = y0 + ly < p.H && x0 + lx < p.W_;
+            const int gy = in ? y0 + ly + p.PHz : 0, gx = in ? x0 + lx + p.PWz : 0;
+            const _Float16* src = Z + (((long)b * Hz + gy) * Wz + gx) * C + ((pos ^ wswz<C>(row)) * 8);
+            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src), LDS_PTR(zd + (size_t)(i - lane) * 16), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src + z_lo), LDS_PTR(zd + PLN + (size_t)(i - lane) * 16), 16, 0, 0);
+        }
+    };
+    f32x4 acc[MAXU][CT][CIG], accx[MAXU][CT][CIG];
+#pragma unroll
+    for (int u = 0; u < MAXU; ++u)
+#pragma unroll
+        for (int i = 0; i < CT; ++i)
+#pragma unroll
+            for (int j = 0; j < CIG; ++j) { acc[u][i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; accx[u][i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    const auto* lds3 = (const __attribute__((address_space(3))) char*)LDS_PTR(lds);
+    int buf = 0;
+    if (NBUF == 2 && (int)blockIdx.x < ntiles) load_tile(blockIdx.x, 0);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        if (NBUF == 1) {
+            __syncthreads();                                       // every wavefront is done with the previous tile
+            load_tile(tile, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (NBUF == 2 && tile + (int)gridDim.x < ntiles) load_tile(tile + gridDim.x, buf ^ 1);
+        const auto* xh = lds3 + (size_t)buf * BUF;
+        const auto* zh = xh + (size_t)NX * 16;
+        for (int ks = 0; ks < TR / 2; ++ks) {                      // 32 positions per step: tile rows 2ks (elements 0-3) and 2ks+1 (4-7)
+            f16x8 ah[CT], al[CT];
+#pragma unroll
+            for (int i = 0; i < CT; ++i) {
+                ah[i] = tr_frag<C>(zh, 32 * ks + 4 * g, 32 * ks + 16 + 4 * g, i * 16, q, pp);
+                al[i] = tr_frag<C>(zh + PLN, 32 * ks + 4 * g, 32 * ks + 16 + 4 * g, i * 16, q, pp);
+            }
+#pragma unroll
+            for (int u = 0; u < MAXU; ++u) {
+                const int unit = wv + 4 * u;                       // wave-uniform
+                if (unit >= 18) break;
+                const int t = unit >> 1, cig = unit & 1, kh = t / 3, kw = t - kh * 3;
+                const int r0 = (2 * ks + kh) * PR + kw + 4 * g, r1 = r0 + PR;
+#pragma unroll
+                for (int j = 0; j < CIG; ++j) {
+                    const f16x8 bh = tr_frag<C>(xh, r0, r1, (cig * CIG + j) * 16, q, pp);
+                    const f16x8 bl = tr_frag<C>(xh + PLN, r0, r1, (cig * CIG + j) * 16, q, pp);
+#pragma unroll
+                    for (int i = 0; i < CT; ++i) {
+                        accx[u][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl, accx[u][i][j], 0, 0, 0);
+                        acc[u][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh, acc[u][i][j], 0, 0, 0);
+                        accx[u][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh, accx[u][i][j], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        if (NBUF == 2) buf ^= 1;
+    }
+    // partial[blk][t][co][ci]: D row = co (4g + r), column = ci (fr)
+    float* out = p.partial + (size_t)blockIdx.x * 9 * C * C;
+#pragma unroll
+    for (int u = 0; u < MAXU; ++u) {
+        const int unit = wv + 4 * u;
+        if (unit >= 18) break;
+        const int t = unit >> 1, cig = unit & 1;
+#pragma unroll
+        for (int i = 0; i < CT; ++i)
+#pragma unroll
+            for (int j = 0; j < CIG; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    out[((size_t)t * C + i * 16 + 4 * g + r) * C + (cig * CIG + j) * 16 + fr] = fmaf(accx[u][i][j][r], 1.f / 2048.f, acc[u][i][j][r]);
+    }
+}
+
 // partial [nparts][n] -> out[n], one wavefront per output, fixed shuffle tree in fp64
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, int nparts, int n, float* __restrict__ out) {
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -164,6 +270,28 @@ extern "C" int advh_conv_wgrad2d_f16(const advh_wgrad2d_desc* d, int C, float* d
     hipStream_t s = (hipStream_t)stream;
     if (ci) hipLaunchKernelGGL(conv_wgrad2d_kernel<64>, dim3(grid), dim3(256), lds, s, *d);
     else hipLaunchKernelGGL(conv_wgrad2d_kernel<32>, dim3(grid), dim3(256), lds, s, *d);
+    const int n = 9 * C * C;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((n + 3) / 4), dim3(256), 0, s, d->partial, grid, n, dw);
+    return ADVH_LAUNCH_CHECK();
+}
+
+extern "C" int advh_conv_wgrad2d_split(const advh_wgrad2d_desc* d, int C, int64_t x_lo, int64_t dz_lo, float* dw, advh_stream_t stream) {
+    if (!d || !d->X || !d->DZ || !d->partial || !dw || d->B <= 0 || d->H <= 0 || d->W_ <= 0 || d->PHx < 1 || d->PWx < 1 ||
+        d->PHz < 1 || d->PWz < 1 || x_lo <= 0 || dz_lo <= 0 || x_lo % 8 || dz_lo % 8)
+        return ADVH_EINVAL;
+    if (C != 32 && C != 64) return ADVH_EUNSUPPORTED;
+    const int grid = advh_conv_wgrad2d_parts(C, d->B, d->H, d->W_);
+    hipStream_t s = (hipStream_t)stream;
+    if (C == 32) {
+        constexpr int lds = 2 * ((((18 * 18 * 4 + 63) & ~63) + 256 * 4) * 16);                   // one buffer, two planes
+        if (advh_ensure_lds((const void*)conv_wgrad2d_x3_kernel<32, 16, 1>) != ADVH_OK) return ADVH_ELAUNCH;
+        hipLaunchKernelGGL((conv_wgrad2d_x3_kernel<32, 16, 1>), dim3(grid), dim3(256), lds, s, *d, (long)x_lo, (long)dz_lo);
+    } else {
+        constexpr int lds = 2 * 2 * ((((10 * 18 * 8 + 63) & ~63) + 128 * 8) * 16);               // two buffers, two planes
+        static_assert(lds <= 160 * 1024, "two-slot ring");
+        if (advh_ensure_lds((const void*)conv_wgrad2d_x3_kernel<64, 8, 2>) != ADVH_OK) return ADVH_ELAUNCH;
+        hipLaunchKernelGGL((conv_wgrad2d_x3_kernel<64, 8, 2>), dim3(grid), dim3(256), lds, s, *d, (long)x_lo, (long)dz_lo);
+    }
     const int n = 9 * C * C;
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((n + 3) / 4), dim3(256), 0, s, d->partial, grid, n, dw);
     return ADVH_LAUNCH_CHECK();
