@@ -592,10 +592,15 @@ typedef struct advh_wgrad2d_desc {
 } advh_wgrad2d_desc;
 int advh_conv_wgrad2d_parts(int C, int B, int H, int W);
 int advh_conv_wgrad2d_f16(const advh_wgrad2d_desc* d, int C, float* dw, advh_stream_t stream);
-/* The same weight gradient in the fp32-class mode: X and DZ are split-format maps (lo plane x_lo / dz_lo elements behind the hi plane),
- * three MFMAs per fragment pair (the arithmetic of the x3 GEMM), fp32 partials and the same fixed-order reduction.  Replaces four operand
- * transposes + a split-K GEMM per layer (train_addvisor.py:376 loss.backward() through addvisor.py:20-24).  */
-int advh_conv_wgrad2d_split(const advh_wgrad2d_desc* d, int C, int64_t x_lo, int64_t dz_lo, float* dw, advh_stream_t stream);
+/* The same weight gradient in the fp32-class mode, per channel-slice pair: X and DZ are split-format maps (lo plane x_lo / dz_lo elements behind
+ * the hi plane) with Cx / Cz channels; the launch computes dw[kh*3+kw][co][ci] for co in [cz0, cz0 + CO), ci in [cx0, cx0 + CI), CI, CO in
+ * {32, 64} -- three MFMAs per fragment pair (the arithmetic of the x3 GEMM), fp32 partials (advh_conv_wgrad2d_split_parts(...) * 9*CO*CI floats)
+ * and the same fixed-order reduction; dw: 9*CO*CI floats.  A wider layer or one with concatenated sources (addvisor.py:63-75 torch.cat) is covered
+ * slice pair by slice pair.  Replaces four operand transposes + a split-K GEMM per layer (train_addvisor.py:376 loss.backward() through
+ * addvisor.py:20-24).  */
+int advh_conv_wgrad2d_split_parts(int CI, int CO, int B, int H, int W);
+int advh_conv_wgrad2d_split(const advh_wgrad2d_desc* d, int CI, int CO, int Cx, int cx0, int Cz, int cz0, int64_t x_lo, int64_t dz_lo,
+                            float* dw, advh_stream_t stream);
 
 /* One fused HiFi-GAN ResBlock1 step for the 32- / 64-channel stages (speechbrain HifiganGenerator via hifigan.py:106-110,
  * 180): out = x + conv2(lrelu(conv1(lrelu(x)))) on a zero-haloed channels-last fp16 map [M][C] (rows m with

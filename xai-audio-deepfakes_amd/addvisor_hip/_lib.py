@@ -83,7 +83,8 @@ SIGNATURES = {
     "advh_unet_stem_wgrad": (_i, [_p, _i, _i, _i, _i, _i, _p, _i, _i, _p, _p, _p]),
     "advh_conv_wgrad2d_parts": (_i, [_i, _i, _i, _i]),
     "advh_conv_wgrad2d_f16": (_i, [_p, _i, _p, _p]),
-    "advh_conv_wgrad2d_split": (_i, [_p, _i, _i64, _i64, _p, _p]),
+    "advh_conv_wgrad2d_split_parts": (_i, [_i, _i, _i, _i, _i]),
+    "advh_conv_wgrad2d_split": (_i, [_p, _i, _i, _i, _i, _i, _i, _i64, _i64, _p, _p]),
     "advh_resblock_pair_lds_bytes": (_i, [_i, _i, _i]),
     "advh_resblock_pair_f16": (_i, [_p, _i, _p]),
     "advh_conv_taps_tile": (_i, [_i, _i, _i]),

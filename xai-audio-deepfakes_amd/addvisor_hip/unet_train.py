@@ -253,13 +253,30 @@ class HipUNetTrain:
             lo += m[s].C
         Cin = sum(m[s].C for s in srcs)
         L["Cin"] = Cin
-        # ---- wgrad, 3x3 stride-1 square 32 / 64-channel layers: LDS-tile kernel with transposing operand reads, no copies
+        # ---- wgrad, 3x3 stride-1 layers: LDS-tile kernel with transposing operand reads, no operand copies.  fp16: square 32 / 64-channel
+        # layers; fp32-class: every layer whose sources and output have a multiple of 32 channels, one launch per (source slice, output slice)
+        # pair of 32 / 64 channels (csrc/conv_wgrad.hip)
         f0 = m[srcs[0]]
-        if (WGRAD_TILES and len(srcs) == 1 and k == (3, 3) and stride == (1, 1) and dil == (1, 1) and Cin == Cout and Cout in (32, 64)
-                and f0.PH >= 1 and f0.PW >= 1):
+        plain33 = WGRAD_TILES and k == (3, 3) and stride == (1, 1) and dil == (1, 1)
+        if (plain33 and not sp and len(srcs) == 1 and Cin == Cout and Cout in (32, 64) and f0.PH >= 1 and f0.PW >= 1):
             nparts = _lib.lib().advh_conv_wgrad2d_parts(Cout, B, Hd, Wd)
             L["wg2d"] = Wgrad2dDesc(B=B, H=Hd, W_=Wd, PHx=f0.PH, PWx=f0.PW, PHz=pph, PWz=ppw)
             L["wg2d_part"] = torch.empty(nparts * 9 * Cout * Cout, dtype=torch.float32, device=dev)
+            return L
+        if (plain33 and sp and Cout % 32 == 0 and pph >= 1 and ppw >= 1
+                and all(m[s_].C % 32 == 0 and m[s_].PH >= 1 and m[s_].PW >= 1 for s_ in srcs)):
+            cuts = lambda n: [(o, 64) for o in range(0, n - n % 64, 64)] + ([(n - 32, 32)] if n % 64 else [])
+            pairs, base, nmax = [], 0, 0
+            for s_ in srcs:
+                f = m[s_]
+                d2 = Wgrad2dDesc(B=B, H=Hd, W_=Wd, PHx=f.PH, PWx=f.PW, PHz=pph, PWz=ppw)
+                for cx0, CI in cuts(f.C):
+                    for cz0, CO in cuts(Cout):
+                        pairs.append((s_, d2, CI, CO, cx0, cz0, base))
+                        nmax = max(nmax, _lib.lib().advh_conv_wgrad2d_split_parts(CI, CO, B, Hd, Wd) * 9 * CI * CO)
+                base += f.C
+            L["wg2d_pairs"] = pairs
+            L["wg2d_part"] = torch.empty(nmax, dtype=torch.float32, device=dev)
             return L
         # ---- wgrad: position-major operands on the common grid (dz's interior grid + vertical tap halo, width % 8 == 0)
         Hg, Wg, GH = Hd + (KH - 1) * dh, G.round_up(Wd, 8), ph
@@ -474,16 +491,23 @@ class HipUNetTrain:
                 continue
             KH, KW = L["k"]
             # ---- wgrad
-            if "wg2d" in L:
+            if "wg2d_pairs" in L:
+                Cn, Cin = z[dst].C, L["Cin"]
+                dwf = torch.empty(Cn, Cin, 3, 3, dtype=torch.float32, device=self.dev)
+                for sname, d2, CI, CO, cx0, cz0, base in L["wg2d_pairs"]:
+                    xm = m[sname]
+                    d2.X, d2.DZ, d2.partial = xm.t.data_ptr(), dzm.t.data_ptr(), L["wg2d_part"].data_ptr()
+                    dw9 = torch.empty(9, CO, CI, dtype=torch.float32, device=self.dev)
+                    _lib.check(lib.advh_conv_wgrad2d_split(C.byref(d2), CI, CO, xm.C, cx0, Cn, cz0, xm.t.stride(0), dzm.t.stride(0),
+                                                            dw9.data_ptr(), st), "advh_conv_wgrad2d_split")
+                    dwf[cz0:cz0 + CO, base + cx0:base + cx0 + CI] = dw9.view(3, 3, CO, CI).permute(2, 3, 0, 1)
+                grads[L["cname"] + ".weight"] = (dwf / S)[:, :w.shape[1]].contiguous()
+            elif "wg2d" in L:
                 d2 = L["wg2d"]
                 d2.X, d2.DZ, d2.partial = m[L["srcs"][0]].t.data_ptr(), dzm.t.data_ptr(), L["wg2d_part"].data_ptr()
                 Cn = z[dst].C
                 dw9 = torch.empty(9, Cn, Cn, dtype=torch.float32, device=self.dev)
-                if self.split:
-                    xm = m[L["srcs"][0]].t
-                    _lib.check(lib.advh_conv_wgrad2d_split(C.byref(d2), Cn, xm.stride(0), dzm.t.stride(0), dw9.data_ptr(), st), "advh_conv_wgrad2d_split")
-                else:
-                    _lib.check(lib.advh_conv_wgrad2d_f16(C.byref(d2), Cn, dw9.data_ptr(), st), "advh_conv_wgrad2d_f16")
+                _lib.check(lib.advh_conv_wgrad2d_f16(C.byref(d2), Cn, dw9.data_ptr(), st), "advh_conv_wgrad2d_f16")
                 grads[L["cname"] + ".weight"] = (dw9.view(3, 3, Cn, Cn).permute(2, 3, 0, 1) / S).contiguous()
             else:
                 self._wgrad_gemm(L, m, z, dzm, dst, w, grads, S)

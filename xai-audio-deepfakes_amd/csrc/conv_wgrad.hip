@@ -137,16 +137,21 @@ __global__ __launch_bounds__(256) void conv_wgrad2d_kernel(const advh_wgrad2d_de
 // its A operand is re-read once per vertical tap (profiles/r03_train_f32_kernel_summary.txt).  C = 32: 16 x 16-position tiles, one buffer
 // (74 KiB), two workgroups per CU hide each other's loads; C = 64: 320 accumulator registers => one wavefront per SIMD, 8 x 16-position tiles
 // in a two-slot ring (156 KiB) so that the next tile's DMA runs under the MFMAs.
-template <int C, int TR, int NBUF>
-__global__ __launch_bounds__(256) void conv_wgrad2d_x3_kernel(const advh_wgrad2d_desc p, long x_lo, long z_lo) {
-    constexpr int CH = C / 8, CT = C / 16, CIG = CT / 2, PR = 18, SRX = (TR + 2) * PR, SRZ = TR * 16, MAXU = 5;
-    constexpr int NX = (SRX * CH + 63) & ~63, NZ = SRZ * CH;      // 16-byte chunks per plane and buffer
+// CI input channels (a slice [cx0, cx0 + CI) of a map with Cx channels) x CO output channels (slice [cz0, cz0 + CO) of the Cz-channel dz
+// map): wider layers and concatenated sources are covered slice pair by slice pair (addvisor_hip/unet_train.py), each launch streaming its two
+// slices once -- (CI + CO) x 4 bytes per position for 9 x CI x CO x 3 MFMA-MACs, against (128 + 128) x 4 bytes per 128 x 128 MACs of a split-K
+// GEMM tile whose operands had to be transposed first.
+template <int CI, int CO, int TR, int NBUF>
+__global__ __launch_bounds__(256) void conv_wgrad2d_x3_kernel(const advh_wgrad2d_desc p, int Cx, int cx0, int Cz, int cz0, long x_lo, long z_lo) {
+    constexpr int CHX = CI / 8, CHZ = CO / 8, CT = CO / 16, CIG = CI / 32, PR = 18, SRX = (TR + 2) * PR, SRZ = TR * 16, MAXU = 5;
+    constexpr int NX = (SRX * CHX + 63) & ~63, NZ = SRZ * CHZ;    // 16-byte chunks per plane and buffer
     constexpr int PLN = (NX + NZ) * 16, BUF = 2 * PLN;            // bytes of one plane / of one buffer (hi plane, lo plane)
+    static_assert(NZ % 64 == 0, "whole wavefronts of DMA pieces");
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3, fr = lane & 15;
-    const _Float16* X = (const _Float16*)p.X;
-    const _Float16* Z = (const _Float16*)p.DZ;
+    const _Float16* X = (const _Float16*)p.X + cx0;
+    const _Float16* Z = (const _Float16*)p.DZ + cz0;
     const int Hx = p.H + 2 * p.PHx, Wx = p.W_ + 2 * p.PWx, Hz = p.H + 2 * p.PHz, Wz = p.W_ + 2 * p.PWz;
     const int tx = (p.W_ + 15) / 16, ty = (p.H + TR - 1) / TR, ntiles = p.B * ty * tx;
     auto load_tile = [&](int tile, int buf) {
@@ -154,19 +159,19 @@ __global__ __launch_bounds__(256) void conv_wgrad2d_x3_kernel(const advh_wgrad2d
         char* xd = lds + (size_t)buf * BUF;
         char* zd = xd + (size_t)NX * 16;
         for (int i = tid; i < NX; i += 256) {                      // (TR + 2) x 18 input patch; rows outside the map are clamped (finite)
-            int row = i / CH, pos = i % CH;
+            int row = i / CHX, pos = i % CHX;
             if (row >= SRX) row = 0;
             int gy = min(y0 + p.PHx - 1 + row / PR, Hx - 1), gx = min(x0 + p.PWx - 1 + row % PR, Wx - 1);
-            const _Float16* src = X + (((long)b * Hx + gy) * Wx + gx) * C + ((pos ^ wswz<C>(i / CH)) * 8);
+            const _Float16* src = X + (((long)b * Hx + gy) * Wx + gx) * Cx + ((pos ^ wswz<CI>(i / CHX)) * 8);
             __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src), LDS_PTR(xd + (size_t)(i - lane) * 16), 16, 0, 0);
             __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src + x_lo), LDS_PTR(xd + PLN + (size_t)(i - lane) * 16), 16, 0, 0);
         }
         for (int i = tid; i < NZ; i += 256) {                      // TR x 16 dz tile; positions outside the image read a halo zero
-            const int row = i / CH, pos = i % CH;
+            const int row = i / CHZ, pos = i % CHZ;
             const int ly = row >> 4, lx = row & 15;
             const bool in = y0 + ly < p.H && x0 + lx < p.W_;
             const int gy = in ? y0 + ly + p.PHz : 0, gx = in ? x0 + lx + p.PWz : 0;
-            const _Float16* src = Z + (((long)b * Hz + gy) * Wz + gx) * C + ((pos ^ wswz<C>(row)) * 8);
+            const _Float16* src = Z + (((long)b * Hz + gy) * Wz + gx) * Cz + ((pos ^ wswz<CO>(row)) * 8);
             __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src), LDS_PTR(zd + (size_t)(i - lane) * 16), 16, 0, 0);
             __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src + z_lo), LDS_PTR(zd + PLN + (size_t)(i - lane) * 16), 16, 0, 0);
         }
@@ -195,8 +200,8 @@ __global__ __launch_bounds__(256) void conv_wgrad2d_x3_kernel(const advh_wgrad2d
             f16x8 ah[CT], al[CT];
 #pragma unroll
             for (int i = 0; i < CT; ++i) {
-                ah[i] = tr_frag<C>(zh, 32 * ks + 4 * g, 32 * ks + 16 + 4 * g, i * 16, q, pp);
-                al[i] = tr_frag<C>(zh + PLN, 32 * ks + 4 * g, 32 * ks + 16 + 4 * g, i * 16, q, pp);
+                ah[i] = tr_frag<CO>(zh, 32 * ks + 4 * g, 32 * ks + 16 + 4 * g, i * 16, q, pp);
+                al[i] = tr_frag<CO>(zh + PLN, 32 * ks + 4 * g, 32 * ks + 16 + 4 * g, i * 16, q, pp);
             }
 #pragma unroll
             for (int u = 0; u < MAXU; ++u) {
@@ -206,8 +211,8 @@ __global__ __launch_bounds__(256) void conv_wgrad2d_x3_kernel(const advh_wgrad2d
                 const int r0 = (2 * ks + kh) * PR + kw + 4 * g, r1 = r0 + PR;
 #pragma unroll
                 for (int j = 0; j < CIG; ++j) {
-                    const f16x8 bh = tr_frag<C>(xh, r0, r1, (cig * CIG + j) * 16, q, pp);
-                    const f16x8 bl = tr_frag<C>(xh + PLN, r0, r1, (cig * CIG + j) * 16, q, pp);
+                    const f16x8 bh = tr_frag<CI>(xh, r0, r1, (cig * CIG + j) * 16, q, pp);
+                    const f16x8 bl = tr_frag<CI>(xh + PLN, r0, r1, (cig * CIG + j) * 16, q, pp);
 #pragma unroll
                     for (int i = 0; i < CT; ++i) {
                         accx[u][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl, accx[u][i][j], 0, 0, 0);
@@ -220,7 +225,7 @@ __global__ __launch_bounds__(256) void conv_wgrad2d_x3_kernel(const advh_wgrad2d
         if (NBUF == 2) buf ^= 1;
     }
     // partial[blk][t][co][ci]: D row = co (4g + r), column = ci (fr)
-    float* out = p.partial + (size_t)blockIdx.x * 9 * C * C;
+    float* out = p.partial + (size_t)blockIdx.x * 9 * CO * CI;
 #pragma unroll
     for (int u = 0; u < MAXU; ++u) {
         const int unit = wv + 4 * u;
@@ -232,7 +237,7 @@ __global__ __launch_bounds__(256) void conv_wgrad2d_x3_kernel(const advh_wgrad2d
             for (int j = 0; j < CIG; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    out[((size_t)t * C + i * 16 + 4 * g + r) * C + (cig * CIG + j) * 16 + fr] = fmaf(accx[u][i][j][r], 1.f / 2048.f, acc[u][i][j][r]);
+                    out[((size_t)t * CO + i * 16 + 4 * g + r) * CI + (cig * CIG + j) * 16 + fr] = fmaf(accx[u][i][j][r], 1.f / 2048.f, acc[u][i][j][r]);
     }
 }
 
@@ -275,24 +280,40 @@ extern "C" int advh_conv_wgrad2d_f16(const advh_wgrad2d_desc* d, int C, float* d
     return ADVH_LAUNCH_CHECK();
 }
 
-extern "C" int advh_conv_wgrad2d_split(const advh_wgrad2d_desc* d, int C, int64_t x_lo, int64_t dz_lo, float* dw, advh_stream_t stream) {
+template <int CI, int CO, int TR, int NBUF>
+static int launch_wgrad2d_x3(const advh_wgrad2d_desc& d, int Cx, int cx0, int Cz, int cz0, long x_lo, long z_lo, int grid, hipStream_t s) {
+    constexpr int lds = NBUF * 2 * (((((TR + 2) * 18 * (CI / 8) + 63) & ~63) + TR * 16 * (CO / 8)) * 16);
+    static_assert(lds <= 160 * 1024, "tile buffers");
+    if (advh_ensure_lds((const void*)conv_wgrad2d_x3_kernel<CI, CO, TR, NBUF>) != ADVH_OK) return ADVH_ELAUNCH;
+    hipLaunchKernelGGL((conv_wgrad2d_x3_kernel<CI, CO, TR, NBUF>), dim3(grid), dim3(256), lds, s, d, Cx, cx0, Cz, cz0, x_lo, z_lo);
+    return ADVH_OK;
+}
+
+extern "C" int advh_conv_wgrad2d_split_parts(int CI, int CO, int B, int H, int W) {
+    const int TR = (CI == 32 && CO == 32) ? 16 : 8;
+    const long ntiles = (long)B * ((H + TR - 1) / TR) * ((W + 15) / 16);
+    const long grid = 256L * ((CI == 32 && CO == 32) ? 2 : 1);
+    return (int)(ntiles < grid ? ntiles : grid);
+}
+
+extern "C" int advh_conv_wgrad2d_split(const advh_wgrad2d_desc* d, int CI, int CO, int Cx, int cx0, int Cz, int cz0, int64_t x_lo,
+                                       int64_t dz_lo, float* dw, advh_stream_t stream) {
     if (!d || !d->X || !d->DZ || !d->partial || !dw || d->B <= 0 || d->H <= 0 || d->W_ <= 0 || d->PHx < 1 || d->PWx < 1 ||
         d->PHz < 1 || d->PWz < 1 || x_lo <= 0 || dz_lo <= 0 || x_lo % 8 || dz_lo % 8)
         return ADVH_EINVAL;
-    if (C != 32 && C != 64) return ADVH_EUNSUPPORTED;
-    const int grid = advh_conv_wgrad2d_parts(C, d->B, d->H, d->W_);
+    if ((CI != 32 && CI != 64) || (CO != 32 && CO != 64)) return ADVH_EUNSUPPORTED;
+    if (Cx % 8 || Cz % 8 || cx0 % 8 || cz0 % 8 || cx0 < 0 || cz0 < 0 || cx0 + CI > Cx || cz0 + CO > Cz) return ADVH_EINVAL;
+    const int grid = advh_conv_wgrad2d_split_parts(CI, CO, d->B, d->H, d->W_);
     hipStream_t s = (hipStream_t)stream;
-    if (C == 32) {
-        constexpr int lds = 2 * ((((18 * 18 * 4 + 63) & ~63) + 256 * 4) * 16);                   // one buffer, two planes
-        if (advh_ensure_lds((const void*)conv_wgrad2d_x3_kernel<32, 16, 1>) != ADVH_OK) return ADVH_ELAUNCH;
-        hipLaunchKernelGGL((conv_wgrad2d_x3_kernel<32, 16, 1>), dim3(grid), dim3(256), lds, s, *d, (long)x_lo, (long)dz_lo);
-    } else {
-        constexpr int lds = 2 * 2 * ((((10 * 18 * 8 + 63) & ~63) + 128 * 8) * 16);               // two buffers, two planes
-        static_assert(lds <= 160 * 1024, "two-slot ring");
-        if (advh_ensure_lds((const void*)conv_wgrad2d_x3_kernel<64, 8, 2>) != ADVH_OK) return ADVH_ELAUNCH;
-        hipLaunchKernelGGL((conv_wgrad2d_x3_kernel<64, 8, 2>), dim3(grid), dim3(256), lds, s, *d, (long)x_lo, (long)dz_lo);
-    }
-    const int n = 9 * C * C;
+    int rc;
+    // 32 x 32: 16 x 16-position tiles in one buffer (74 KiB), two workgroups per CU hide each other's loads; the wider forms hold 160 - 320
+    // accumulator registers (one wavefront per SIMD) and run 8 x 16-position tiles through a two-slot ring, the next tile's DMA under the MFMAs
+    if (CI == 32 && CO == 32) rc = launch_wgrad2d_x3<32, 32, 16, 1>(*d, Cx, cx0, Cz, cz0, x_lo, dz_lo, grid, s);
+    else if (CI == 64 && CO == 64) rc = launch_wgrad2d_x3<64, 64, 8, 2>(*d, Cx, cx0, Cz, cz0, x_lo, dz_lo, grid, s);
+    else if (CI == 32) rc = launch_wgrad2d_x3<32, 64, 8, 2>(*d, Cx, cx0, Cz, cz0, x_lo, dz_lo, grid, s);
+    else rc = launch_wgrad2d_x3<64, 32, 8, 2>(*d, Cx, cx0, Cz, cz0, x_lo, dz_lo, grid, s);
+    if (rc != ADVH_OK) return rc;
+    const int n = 9 * CO * CI;
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((n + 3) / 4), dim3(256), 0, s, d->partial, grid, n, dw);
     return ADVH_LAUNCH_CHECK();
 }
