@@ -185,3 +185,38 @@ def test_backward_is_deterministic(gpu_device):
     net.forward(mag.to(gpu_device), H=32, W=8); g1 = net.backward(dmask.to(gpu_device))
     net.forward(mag.to(gpu_device), H=32, W=8); g2 = net.backward(dmask.to(gpu_device))     # only the running buffers moved
     assert all(torch.equal(g1[k], g2[k]) for k in g1)
+
+
+@pytest.mark.parametrize("CI,CO,Cx,cx0,Cz,cz0,B,H,W", [(32, 32, 32, 0, 32, 0, 2, 40, 24), (64, 64, 64, 0, 64, 0, 2, 24, 20), (64, 64, 192, 64, 128, 64, 3, 16, 12),
+                                                       (32, 64, 96, 64, 128, 0, 2, 19, 33), (64, 32, 128, 0, 96, 64, 2, 9, 17), (32, 32, 64, 32, 96, 32, 1, 35, 50)])
+def test_wgrad2d_split_slice_pairs(gpu_device, CI, CO, Cx, cx0, Cz, cz0, B, H, W):
+    """``advh_conv_wgrad2d_split`` (csrc/conv_wgrad.hip: transposing LDS reads, three fp16 MFMAs per fragment pair) on one (input slice,
+    output slice) pair of wider split-format maps with different halos, ragged tile edges included, against the fp64 weight gradient of a
+    3x3 "same" convolution (addvisor.py:20-24 under train_addvisor.py:376) on the joined values."""
+    import ctypes as C
+    from addvisor_hip import _lib
+    from addvisor_hip.unet_train import Wgrad2dDesc
+    _lib.init()
+    g = torch.Generator().manual_seed(CI + CO + H)
+    x = G.FMap(B, H, W, Cx, 2, 1, split=True).alloc(gpu_device)
+    z = G.FMap(B, H, W, Cz, 1, 3, split=True).alloc(gpu_device)
+    xs, zs = G.split_planes(torch.randn(B, H, W, Cx, generator=g)), G.split_planes(torch.randn(B, H, W, Cz, generator=g) * 0.3)
+    x.t[:, :, 2:2 + H, 1:1 + W] = xs.to(gpu_device)
+    z.t[:, :, 1:1 + H, 3:3 + W] = zs.to(gpu_device)
+    lib = _lib.lib()
+    parts = lib.advh_conv_wgrad2d_split_parts(CI, CO, B, H, W)
+    part = torch.empty(parts * 9 * CI * CO, dtype=torch.float32, device=gpu_device)
+    dw = torch.full((9, CO, CI), float("nan"), dtype=torch.float32, device=gpu_device)
+    d = Wgrad2dDesc(B=B, H=H, W_=W, PHx=2, PWx=1, PHz=1, PWz=3)
+    d.X, d.DZ, d.partial = x.t.data_ptr(), z.t.data_ptr(), part.data_ptr()
+    _lib.check(lib.advh_conv_wgrad2d_split(C.byref(d), CI, CO, Cx, cx0, Cz, cz0, x.t.stride(0), z.t.stride(0), dw.data_ptr(),
+                                            torch.cuda.current_stream().cuda_stream), "advh_conv_wgrad2d_split")
+    torch.cuda.synchronize()
+    xj = G.join_planes(xs).double()[..., cx0:cx0 + CI].permute(0, 3, 1, 2)          # [B, CI, H, W]
+    zj = G.join_planes(zs).double()[..., cz0:cz0 + CO].permute(0, 3, 1, 2)
+    ref = nngrad.conv2d_weight(xj, (CO, CI, 3, 3), zj, padding=1)                    # [CO, CI, 3, 3]
+    got = dw.cpu().double().view(3, 3, CO, CI).permute(2, 3, 0, 1)
+    assert torch.isfinite(got).all()
+    err = float((got - ref).abs().max() / ref.abs().max())
+    print(f"wgrad2d split {CI}x{CO} slice of {Cx}x{Cz}: rel err {err:.2e}")
+    assert err < 2e-6

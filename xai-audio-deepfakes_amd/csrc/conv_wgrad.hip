@@ -141,9 +141,12 @@ __global__ __launch_bounds__(256) void conv_wgrad2d_kernel(const advh_wgrad2d_de
 // map): wider layers and concatenated sources are covered slice pair by slice pair (addvisor_hip/unet_train.py), each launch streaming its two
 // slices once -- (CI + CO) x 4 bytes per position for 9 x CI x CO x 3 MFMA-MACs, against (128 + 128) x 4 bytes per 128 x 128 MACs of a split-K
 // GEMM tile whose operands had to be transposed first.
-template <int CI, int CO, int TR, int NBUF>
-__global__ __launch_bounds__(256) void conv_wgrad2d_x3_kernel(const advh_wgrad2d_desc p, int Cx, int cx0, int Cz, int cz0, long x_lo, long z_lo) {
-    constexpr int CHX = CI / 8, CHZ = CO / 8, CT = CO / 16, CIG = CI / 32, PR = 18, SRX = (TR + 2) * PR, SRZ = TR * 16, MAXU = 5;
+// NW wavefronts: 4 (a tap's input-channel tiles in two units, 18 units) or -- CI = 64 only -- 8 (one unit per tap and 16-channel input tile, 36 units:
+// half the accumulators per wavefront, so two wavefronts share a SIMD and cover each other's LDS latency).
+template <int CI, int CO, int TR, int NBUF, int NW>
+__global__ __launch_bounds__(64 * NW) void conv_wgrad2d_x3_kernel(const advh_wgrad2d_desc p, int Cx, int cx0, int Cz, int cz0, long x_lo, long z_lo) {
+    constexpr int CHX = CI / 8, CHZ = CO / 8, CT = CO / 16, NTI = CI / 16, UPT = NW == 4 ? 2 : NTI, CIG = NTI / UPT, NUNIT = 9 * UPT;
+    constexpr int PR = 18, SRX = (TR + 2) * PR, SRZ = TR * 16, MAXU = (NUNIT + NW - 1) / NW, NTH = 64 * NW;
     constexpr int NX = (SRX * CHX + 63) & ~63, NZ = SRZ * CHZ;    // 16-byte chunks per plane and buffer
     constexpr int PLN = (NX + NZ) * 16, BUF = 2 * PLN;            // bytes of one plane / of one buffer (hi plane, lo plane)
     static_assert(NZ % 64 == 0, "whole wavefronts of DMA pieces");
@@ -158,7 +161,7 @@ __global__ __launch_bounds__(256) void conv_wgrad2d_x3_kernel(const advh_wgrad2d
         const int x0 = (tile % tx) * 16, r_ = tile / tx, y0 = (r_ % ty) * TR, b = r_ / ty;
         char* xd = lds + (size_t)buf * BUF;
         char* zd = xd + (size_t)NX * 16;
-        for (int i = tid; i < NX; i += 256) {                      // (TR + 2) x 18 input patch; rows outside the map are clamped (finite)
+        for (int i = tid; i < NX; i += NTH) {                      // (TR + 2) x 18 input patch; rows outside the map are clamped (finite)
             int row = i / CHX, pos = i % CHX;
             if (row >= SRX) row = 0;
             int gy = min(y0 + p.PHx - 1 + row / PR, Hx - 1), gx = min(x0 + p.PWx - 1 + row % PR, Wx - 1);
@@ -166,7 +169,7 @@ __global__ __launch_bounds__(256) void conv_wgrad2d_x3_kernel(const advh_wgrad2d
             __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src), LDS_PTR(xd + (size_t)(i - lane) * 16), 16, 0, 0);
             __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src + x_lo), LDS_PTR(xd + PLN + (size_t)(i - lane) * 16), 16, 0, 0);
         }
-        for (int i = tid; i < NZ; i += 256) {                      // TR x 16 dz tile; positions outside the image read a halo zero
+        for (int i = tid; i < NZ; i += NTH) {                      // TR x 16 dz tile; positions outside the image read a halo zero
             const int row = i / CHZ, pos = i % CHZ;
             const int ly = row >> 4, lx = row & 15;
             const bool in = y0 + ly < p.H && x0 + lx < p.W_;
@@ -196,6 +199,7 @@ __global__ __launch_bounds__(256) void conv_wgrad2d_x3_kernel(const advh_wgrad2d
         if (NBUF == 2 && tile + (int)gridDim.x < ntiles) load_tile(tile + gridDim.x, buf ^ 1);
         const auto* xh = lds3 + (size_t)buf * BUF;
         const auto* zh = xh + (size_t)NX * 16;
+#pragma unroll 1
         for (int ks = 0; ks < TR / 2; ++ks) {                      // 32 positions per step: tile rows 2ks (elements 0-3) and 2ks+1 (4-7)
             f16x8 ah[CT], al[CT];
 #pragma unroll
@@ -205,9 +209,9 @@ __global__ __launch_bounds__(256) void conv_wgrad2d_x3_kernel(const advh_wgrad2d
             }
 #pragma unroll
             for (int u = 0; u < MAXU; ++u) {
-                const int unit = wv + 4 * u;                       // wave-uniform
-                if (unit >= 18) break;
-                const int t = unit >> 1, cig = unit & 1, kh = t / 3, kw = t - kh * 3;
+                const int unit = wv + NW * u;                      // wave-uniform
+                if (unit >= NUNIT) break;
+                const int t = unit / UPT, cig = unit % UPT, kh = t / 3, kw = t - kh * 3;
                 const int r0 = (2 * ks + kh) * PR + kw + 4 * g, r1 = r0 + PR;
 #pragma unroll
                 for (int j = 0; j < CIG; ++j) {
@@ -228,9 +232,9 @@ __global__ __launch_bounds__(256) void conv_wgrad2d_x3_kernel(const advh_wgrad2d
     float* out = p.partial + (size_t)blockIdx.x * 9 * CO * CI;
 #pragma unroll
     for (int u = 0; u < MAXU; ++u) {
-        const int unit = wv + 4 * u;
-        if (unit >= 18) break;
-        const int t = unit >> 1, cig = unit & 1;
+        const int unit = wv + NW * u;
+        if (unit >= NUNIT) break;
+        const int t = unit / UPT, cig = unit % UPT;
 #pragma unroll
         for (int i = 0; i < CT; ++i)
 #pragma unroll
@@ -241,15 +245,23 @@ __global__ __launch_bounds__(256) void conv_wgrad2d_x3_kernel(const advh_wgrad2d
     }
 }
 
-// partial [nparts][n] -> out[n], one wavefront per output, fixed shuffle tree in fp64
+// partial [nparts][n] -> out[n]: one thread per output, the parts added in index order in fp64 (deterministic); consecutive threads read
+// consecutive outputs of one part, so every load instruction covers whole cache lines (the first form gave a wavefront to each output and read
+// the parts with a stride of n floats: 46 us for 256 x 36 864 floats, 3.5 ms of the training step; profiles/r03_train_f32_kernel_summary.txt)
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, int nparts, int n, float* __restrict__ out) {
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     double a = 0.0;
-    for (int pi = lane; pi < nparts; pi += 64) a += (double)partial[(size_t)pi * n + i];
+    int pi = 0;
+    for (; pi + 8 <= nparts; pi += 8) {
+        float v[8];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
-    if (lane == 0) out[i] = (float)a;
+        for (int j = 0; j < 8; ++j) v[j] = partial[(size_t)(pi + j) * n + i];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a += (double)v[j];
+    }
+    for (; pi < nparts; ++pi) a += (double)partial[(size_t)pi * n + i];
+    out[i] = (float)a;
 }
 
 }  // namespace advh
@@ -276,16 +288,16 @@ extern "C" int advh_conv_wgrad2d_f16(const advh_wgrad2d_desc* d, int C, float* d
     if (ci) hipLaunchKernelGGL(conv_wgrad2d_kernel<64>, dim3(grid), dim3(256), lds, s, *d);
     else hipLaunchKernelGGL(conv_wgrad2d_kernel<32>, dim3(grid), dim3(256), lds, s, *d);
     const int n = 9 * C * C;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((n + 3) / 4), dim3(256), 0, s, d->partial, grid, n, dw);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d->partial, grid, n, dw);
     return ADVH_LAUNCH_CHECK();
 }
 
-template <int CI, int CO, int TR, int NBUF>
+template <int CI, int CO, int TR, int NBUF, int NW>
 static int launch_wgrad2d_x3(const advh_wgrad2d_desc& d, int Cx, int cx0, int Cz, int cz0, long x_lo, long z_lo, int grid, hipStream_t s) {
     constexpr int lds = NBUF * 2 * (((((TR + 2) * 18 * (CI / 8) + 63) & ~63) + TR * 16 * (CO / 8)) * 16);
     static_assert(lds <= 160 * 1024, "tile buffers");
-    if (advh_ensure_lds((const void*)conv_wgrad2d_x3_kernel<CI, CO, TR, NBUF>) != ADVH_OK) return ADVH_ELAUNCH;
-    hipLaunchKernelGGL((conv_wgrad2d_x3_kernel<CI, CO, TR, NBUF>), dim3(grid), dim3(256), lds, s, d, Cx, cx0, Cz, cz0, x_lo, z_lo);
+    if (advh_ensure_lds((const void*)conv_wgrad2d_x3_kernel<CI, CO, TR, NBUF, NW>) != ADVH_OK) return ADVH_ELAUNCH;
+    hipLaunchKernelGGL((conv_wgrad2d_x3_kernel<CI, CO, TR, NBUF, NW>), dim3(grid), dim3(64 * NW), lds, s, d, Cx, cx0, Cz, cz0, x_lo, z_lo);
     return ADVH_OK;
 }
 
@@ -306,14 +318,15 @@ extern "C" int advh_conv_wgrad2d_split(const advh_wgrad2d_desc* d, int CI, int C
     const int grid = advh_conv_wgrad2d_split_parts(CI, CO, d->B, d->H, d->W_);
     hipStream_t s = (hipStream_t)stream;
     int rc;
-    // 32 x 32: 16 x 16-position tiles in one buffer (74 KiB), two workgroups per CU hide each other's loads; the wider forms hold 160 - 320
-    // accumulator registers (one wavefront per SIMD) and run 8 x 16-position tiles through a two-slot ring, the next tile's DMA under the MFMAs
-    if (CI == 32 && CO == 32) rc = launch_wgrad2d_x3<32, 32, 16, 1>(*d, Cx, cx0, Cz, cz0, x_lo, dz_lo, grid, s);
-    else if (CI == 64 && CO == 64) rc = launch_wgrad2d_x3<64, 64, 8, 2>(*d, Cx, cx0, Cz, cz0, x_lo, dz_lo, grid, s);
-    else if (CI == 32) rc = launch_wgrad2d_x3<32, 64, 8, 2>(*d, Cx, cx0, Cz, cz0, x_lo, dz_lo, grid, s);
-    else rc = launch_wgrad2d_x3<64, 32, 8, 2>(*d, Cx, cx0, Cz, cz0, x_lo, dz_lo, grid, s);
+    // 32 x 32: 16 x 16-position tiles in one buffer (74 KiB), two workgroups per CU hide each other's loads; the wider forms run 8 x 16-position
+    // tiles through a two-slot ring (the next tile's DMA under the MFMAs), CI = 64 with eight wavefronts (64 x 64 at 64 x 128 x 196: 455 us
+    // against 554 us with four, 64 x 64 x 98: 112 against 156; profiles/r03_wgrad_x3.txt)
+    if (CI == 32 && CO == 32) rc = launch_wgrad2d_x3<32, 32, 16, 1, 4>(*d, Cx, cx0, Cz, cz0, x_lo, dz_lo, grid, s);
+    else if (CI == 64 && CO == 64) rc = launch_wgrad2d_x3<64, 64, 8, 2, 8>(*d, Cx, cx0, Cz, cz0, x_lo, dz_lo, grid, s);
+    else if (CI == 32) rc = launch_wgrad2d_x3<32, 64, 8, 2, 4>(*d, Cx, cx0, Cz, cz0, x_lo, dz_lo, grid, s);
+    else rc = launch_wgrad2d_x3<64, 32, 8, 2, 8>(*d, Cx, cx0, Cz, cz0, x_lo, dz_lo, grid, s);
     if (rc != ADVH_OK) return rc;
     const int n = 9 * CO * CI;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((n + 3) / 4), dim3(256), 0, s, d->partial, grid, n, dw);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d->partial, grid, n, dw);
     return ADVH_LAUNCH_CHECK();
 }
