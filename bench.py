@@ -628,14 +628,25 @@ def bench_train(ctx, precision="f32", B=64, steps=5, warmup=2, both=True):
             opt_m.step(); opt_w.step()
             return total
 
+        dist = ctx["dist"]
+
+        def barrier():
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize()
+
         for _ in range(warmup):
             step()
-        torch.cuda.synchronize()
+        barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
             vals.append(step())
-        torch.cuda.synchronize()
+        barrier()
         dt = (time.perf_counter() - t0) / steps
+        if dist is not None:                                   # every rank trains its own replica on its own clips: the slowest rank's time
+            t = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
         vals = [float(v) for v in vals]
         out = {"workload": f"mask-decoder training step (train_addvisor.py:364-381): batch {B} x {AUDIO_LENGTH} s, U-Net forward / backward + LMAC loss "
                            "forward / backward through the frozen wav2vec2-base + two Adam steps, one GPU", "value": round(B / dt, 1), "unit": "clips/s",
