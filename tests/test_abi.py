@@ -51,3 +51,32 @@ def test_no_oracle_import_in_product():
             if f.endswith(".py"):
                 src = open(os.path.join(dp, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+
+
+def test_argument_errors_of_the_round3_entry_points(built):
+    """The error contract of include/addvisor_hip.h (negative return, nothing launched) for the entry points added in round 3:
+    argument validation happens before any HIP call, so it can be exercised without a GPU."""
+    import ctypes as C
+    lib = _lib.lib()
+    EINVAL, EUNSUPPORTED = -1, -4
+    buf = (C.c_float * 64)()
+    p = C.addressof(buf)
+    assert lib.advh_split_f32(None, p, 64, 64, None) == EINVAL
+    assert lib.advh_split_f32(p, p, 8, 64, None) == EINVAL                               # lo plane closer than n elements
+    assert lib.advh_split_f32(p, p, 64, 0, None) == EINVAL
+    assert lib.advh_attention_bwd_split(None, 8, p, 8, p, 8, 1, 16, 64, 1, None) == EINVAL
+    assert lib.advh_attention_bwd_split(p, 8, p, 8, p, 8, 1, 16, 64, 3, None) == EINVAL  # H % heads
+    assert lib.advh_attention_bwd_split(p, 8, p, 8, p, 8, 1, 300, 64, 1, None) == EUNSUPPORTED   # T > 256
+    assert lib.advh_attention_bwd_split(p, 4, p, 8, p, 8, 1, 16, 64, 1, None) == EINVAL  # plane distance not a multiple of 8
+    from addvisor_hip.unet_train import Wgrad2dDesc
+    d = Wgrad2dDesc(B=1, H=8, W_=16, PHx=1, PWx=1, PHz=1, PWz=1)
+    d.X, d.DZ, d.partial = p, p, p
+    assert lib.advh_conv_wgrad2d_split(C.byref(d), 48, 32, 48, 0, 32, 0, 1024, 1024, p, None) == EUNSUPPORTED   # CI not 32 | 64
+    assert lib.advh_conv_wgrad2d_split(C.byref(d), 32, 32, 64, 40, 32, 0, 1024, 1024, p, None) == EINVAL        # slice past the map's channels
+    assert lib.advh_conv_wgrad2d_split(C.byref(d), 32, 32, 32, 0, 32, 0, 0, 1024, p, None) == EINVAL            # no lo plane
+    d.PHx = 0
+    assert lib.advh_conv_wgrad2d_split(C.byref(d), 32, 32, 32, 0, 32, 0, 1024, 1024, p, None) == EINVAL         # the patch needs a halo
+    assert lib.advh_conv_wgrad2d_split_parts(64, 64, 64, 128, 196) == 256 and lib.advh_conv_wgrad2d_split_parts(32, 32, 1, 16, 16) == 1
+    assert lib.advh_set_option(b"attention_bwd_mfma_f32", 1) == 0 and lib.advh_set_option(b"attention_bwd_mfma_f32", 0) == 0
+    assert lib.advh_set_option(b"no_such_option", 1) == EINVAL
+    assert lib.advh_split_overflow(0) == 0                                                # no device initialised: no flag word, reads as clear
