@@ -58,6 +58,7 @@ def parse_args():
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--workload", choices=("explain", "hifigan", "ig", "dataset", "xlsr2b", "train"), default="explain")
     ap.add_argument("--precision", choices=("f32", "f16"), default="f32", help="headline precision of the explain workload")
+    ap.add_argument("--vocoder", action="store_true", help="explain workload with both resyntheses re-rendered by the HiFi-GAN V1 vocoder (the north-star variant) as the headline")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (f16 / hifigan / ig keys)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verbose", action="store_true")
@@ -354,7 +355,7 @@ def committed_traffic(kernel):
 
 def explain_line(ctx):
     args, rank, world = ctx["args"], ctx["rank"], ctx["world"]
-    head = run_explain(ctx, args.precision, args.steps, args.warmup)
+    head = run_explain(ctx, args.precision, args.steps, args.warmup, vocoder=args.vocoder)
     B, L = args.batch, AUDIO_LENGTH * 16000
     prec_txt = {"f32": "fp32-class: split-format (hi + lo * 2^-11) operands, 3 fp16 MFMAs per product, fp32 accumulate / norms / residual",
                 "f16": "fp16 operands, fp32 accumulate / norms / residual"}
@@ -368,6 +369,7 @@ def explain_line(ctx):
                                "+ masked ISTFT x2 + embedder re-forward x2 + LMAC metrics",
                    "batch_per_gpu": B, "clip_samples": L, "embedder": "wav2vec2-base (seeded random weights)",
                    "precision": prec_txt[args.precision], "sharding": f"utterance x{world}",
+                   **({"vocoder": "HiFi-GAN V1 (mel front end + generator) re-renders both resyntheses before the classifier re-forward"} if args.vocoder else {}),
                    "gflop_per_explanation": round(head["flops_step"] / B / 1e9, 1)},
         "lmac": {k: round(v, 6) for k, v in head["metrics"].items()},
         "pipeline_tflops": round(head["flops_step"] * args.steps * world / head["elapsed"] / 1e12, 1),
@@ -375,7 +377,7 @@ def explain_line(ctx):
         "cpu_baseline": None,
     }
     line["roofline_hbm"] = stft_roofline(ctx["dev"], B)        # every rank runs it (identical, a few ms): no rank leaves the others waiting
-    extras = world == 1 and not args.no_extras and not args.tune
+    extras = world == 1 and not args.no_extras and not args.tune and not args.vocoder
     if rank == 0 and world == 1 and not args.no_traffic and not args.tune and head["roofline"]["launches"]:
         kern = head["roofline"]["kernel"]
         nbytes, src = measured_traffic(kern, args.precision, args.batch, args.streams)
