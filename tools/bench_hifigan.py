@@ -37,10 +37,12 @@ if os.environ.get("HIFIGAN_DETAIL"):
             plan.run(src.t, out_h=dst.t, resid=None if resid is None else resid.t, out_h2=None if dst2 is None else dst2.t)
         e1.record(); e1.synchronize()
         ms = e0.elapsed_time(e1) / 3
-        if isinstance(plan, G.ResblockPairPlan):
+        if isinstance(plan, G.ResblockPairX3Plan):
+            key = ("fused_x3", 32, plan.desc.k, plan.desc.dil)
+        elif isinstance(plan, G.ResblockPairPlan):
             key = ("fused", plan.Cn, plan.desc.k, plan.desc.dil)
         elif isinstance(plan, G.TapsPlan):
-            key = ("taps", plan.Cn, plan.desc.ntap, abs(plan.desc.toff[0]))
+            key = ("taps_x3" if plan.split else "taps", plan.Cn, plan.desc.ntap, abs(plan.desc.toff[0]), resid is not None)
         else:
             key = ("gemm", plan.desc.N, plan.K, G.TILE_NAMES[plan.tile], int(plan.ktab_host[plan.desc.a_c0[0] * 0 + max(1, plan.K // 8 // max(1, plan.K // (8 * 8))) - 1] if False else plan.ktab_host[-1]), resid is not None)
         a = agg.setdefault(key, [0, 0.0, 0.0])
