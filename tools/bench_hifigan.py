@@ -42,7 +42,7 @@ if os.environ.get("HIFIGAN_DETAIL"):
         elif isinstance(plan, G.ResblockPairPlan):
             key = ("fused", plan.Cn, plan.desc.k, plan.desc.dil)
         elif isinstance(plan, G.TapsPlan):
-            key = ("taps_x3" if plan.split else "taps", plan.Cn, plan.desc.ntap, abs(plan.desc.toff[0]), resid is not None)
+            key = ("taps_x3" if getattr(plan, "split", False) else "taps", plan.Cn, plan.desc.ntap, abs(plan.desc.toff[0]), resid is not None)
         else:
             key = ("gemm", plan.desc.N, plan.K, G.TILE_NAMES[plan.tile], int(plan.ktab_host[plan.desc.a_c0[0] * 0 + max(1, plan.K // 8 // max(1, plan.K // (8 * 8))) - 1] if False else plan.ktab_host[-1]), resid is not None)
         a = agg.setdefault(key, [0, 0.0, 0.0])

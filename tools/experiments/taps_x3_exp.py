@@ -1,3 +1,4 @@
+"""Ablation script of the reverted conv_taps_x3 experiment (commit 7374ba2; profiles/r03_conv_taps_x3_experiment.txt): needs that commit's kernel."""
 import os, sys, torch, ctypes as C
 sys.path.insert(0, "/root/repo/xai-audio-deepfakes_amd")
 from addvisor_hip import _lib, gemm as G
