@@ -15,7 +15,10 @@ Backward  per layer, in reverse:
           * wgrad: the reduction runs over positions, so both operands are transposed to position-major once
             (``advh_transpose_gather``: the horizontal taps become extra rows, the vertical taps become 8-aligned
             K offsets because the common grid's width is a multiple of 8) and the product is a split-K launch of the
-            same GEMM kernel (``w_ld`` / grid-z batches) with fp32 partial outputs summed afterwards.
+            same GEMM kernel (``w_ld`` / grid-z batches) with fp32 partial outputs summed afterwards.  3x3 stride-1 layers skip all
+            of that: ``advh_conv_wgrad2d_f16`` / ``advh_conv_wgrad2d_split`` read both position-major maps through the transposing
+            LDS load and keep the nine taps' accumulators in registers (fp16: square 32 / 64-channel layers; fp32-class: every layer
+            with 32-multiple channel counts, one launch per (source slice, output slice) pair).
           ConvTranspose2d (kernel = stride): dgrad is a strided convolution, wgrad the same transposed GEMM with the
           sub-pixel taps gathered by the transpose.
 Gradients between kernels are fp16 scaled by a power of two chosen from the incoming mask gradient; sums are fp32/fp64.
@@ -23,9 +26,9 @@ Gradients between kernels are fp16 scaled by a power of two chosen from the inco
 Precision (``precision=``, default ``ADDVISOR_PRECISION`` = f32): the reference trains in fp32 (train_addvisor.py:363-378).
 "f32" = the fp32-class mode: every map above is a split-format plane pair ``[2, B, Hp, Wp, C]`` (hi + lo * 2^-11, ~22 bits),
 the forward convolutions, dgrads and split-K wgrads are the three-MFMA launches (``desc.split``), the BatchNorm / head / stem
-kernels read and write plane pairs, the operand transposes run once per plane -- so LeakyReLU takes the branch the fp32
-reference takes and parameter gradients agree with fp32 autograd to ~1e-5 instead of the fp16 mode's cosine 0.98.  "f16" =
-fp16 maps and gradients (half the bytes, a third of the MFMAs; the LDS-tile wgrad kernel is fp16-only).
+kernels read and write plane pairs, the operand transposes (strided / dilated / up-sampling layers only) run once per plane -- so
+LeakyReLU takes the branch the fp32 reference takes and parameter gradients agree with fp32 autograd to ~1e-5 instead of the fp16
+mode's cosine 0.98.  "f16" = fp16 maps and gradients (half the bytes, a third of the MFMAs).
 """
 from __future__ import annotations
 

@@ -134,9 +134,8 @@ __global__ __launch_bounds__(256) void conv_wgrad2d_kernel(const advh_wgrad2d_de
 // costs three MFMAs (acc += Zh Xh; accx += Zh Xl + Zl Xh; result acc + accx * 2^-11, the arithmetic of gemm_x3_kernel), and the two planes of a
 // tile are staged by the same LDS DMA.  The split-K GEMM it replaces for these layers needed four operand transposes per layer (both planes of
 // x with its three horizontal taps and of dz: 2.2 ms for the 512 x 196 x 32-channel map of a 64-clip batch) and then ran at 58 TFLOP/s because
-// its A operand is re-read once per vertical tap (profiles/r03_train_f32_kernel_summary.txt).  C = 32: 16 x 16-position tiles, one buffer
-// (74 KiB), two workgroups per CU hide each other's loads; C = 64: 320 accumulator registers => one wavefront per SIMD, 8 x 16-position tiles
-// in a two-slot ring (156 KiB) so that the next tile's DMA runs under the MFMAs.
+// its A operand is re-read once per vertical tap (profiles/r03_train_f32_kernel_summary.txt).  Tile shape, buffering and wavefront count per
+// (CI, CO): advh_conv_wgrad2d_split below.
 // CI input channels (a slice [cx0, cx0 + CI) of a map with Cx channels) x CO output channels (slice [cz0, cz0 + CO) of the Cz-channel dz
 // map): wider layers and concatenated sources are covered slice pair by slice pair (addvisor_hip/unet_train.py), each launch streaming its two
 // slices once -- (CI + CO) x 4 bytes per position for 9 x CI x CO x 3 MFMA-MACs, against (128 + 128) x 4 bytes per 128 x 128 MACs of a split-K
