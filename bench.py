@@ -50,11 +50,14 @@ PEAK_NOTE = {"f16": "dense fp16 MFMA peak", "f32": "dense fp16 MFMA peak / 3: th
              "(the native fp32 MFMA peak is 157 TFLOP/s)"}
 
 
+DEFAULT_STEPS = 40
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=DEFAULT_STEPS, help="timed steps (default 40: ~2 s of timed work, past the clock ramp of the first second)")
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--workload", choices=("explain", "hifigan", "ig", "dataset", "xlsr2b", "train"), default="explain")
     ap.add_argument("--precision", choices=("f32", "f16"), default="f32", help="headline precision of the explain workload")
@@ -144,7 +147,7 @@ def main():
     elif args.workload == "ig":
         line = ig_line(ctx, bench_ig(ctx, 16, 160, args.precision))
     elif args.workload == "xlsr2b":
-        r = bench_xlsr2b(ctx, args.precision, args.steps if args.steps != 10 else 3, min(args.warmup, 1) or 1)
+        r = bench_xlsr2b(ctx, args.precision, args.steps if args.steps != DEFAULT_STEPS else 3, min(args.warmup, 1) or 1)
         line = {"metric": "explanations/sec (16 kHz, 4 s clips), XLS-R-2B-width embedder", "value": r["value"],
                 "unit": "explanations/s", "n_gpus": world, "steps": r["steps"], "warmup": 1, "ms_per_step": r["ms_per_step"], "higher_is_better": True,
                 "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic", "config": {"workload": r["workload"]},
