@@ -322,6 +322,8 @@ def test_split_planes_device_matches_host(gpu_device):
     _lib.check_overflow()
     assert dev.shape == host.shape and dev.dtype == torch.float16
     assert torch.equal(dev.cpu(), host)                                              # value-equal planes (a signed zero may differ)
+    off = torch.randn(1 + 4 * 50, generator=g).to(gpu_device)[1:]                    # contiguous view, 4-byte-aligned only: copied first
+    assert off.data_ptr() % 16 and torch.equal(G.split_planes(off).cpu(), G.split_planes(off.cpu()))
     odd = torch.randn(7, 3, generator=g)                                             # numel % 4 != 0: the host formulation
     assert torch.equal(G.split_planes(odd.to(gpu_device)).cpu(), G.split_planes(odd))
     big = x.clone(); big[5, 5] = 1e5

@@ -128,6 +128,8 @@ def split_planes(x: torch.Tensor) -> torch.Tensor:
         # device tensors (the training path's per-step weight refresh): one HIP launch, no host synchronisation; out-of-range
         # values saturate and raise the sticky flag (SplitRangeError at the next _lib.check) instead of the ValueError below
         src = x.detach().contiguous()
+        if src.data_ptr() % 16:                               # a contiguous view at an odd storage offset: the kernel loads float4
+            src = src.clone()
         out = torch.empty((2,) + tuple(src.shape), dtype=torch.float16, device=src.device)
         if src.numel():
             _lib.check(_lib.lib().advh_split_f32(src.data_ptr(), out.data_ptr(), src.numel(), src.numel(),
