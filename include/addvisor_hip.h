@@ -579,6 +579,13 @@ int advh_unet_head_wgrad_split(const float* dlogit, const void* y1, int64_t y_lo
                                advh_stream_t stream);
 int advh_unet_stem_wgrad_split(const void* dz, int64_t dz_lo, int Fq, int Tq, int B, int H, int W, const float* mag, int PH, int PW,
                                float* partial, float* dw, advh_stream_t stream);
+/* Weight gradient of the one skip (magnitude) channel of d1.block.0 -- Conv2d(33, 32, 3, padding 1) on torch.cat([up1(y2), x], 1),
+ * addvisor.py:57-60, 79: dw[co][kh*3+kw] = sum_p dz[p][co] * mag[b][h+kh-1][w+kw-1] over the H x W crop of mag [B][Fq][Tq]; dz [B][H+2PH][W+2PW][32]
+ * (fp16, or a split pair with the lo plane dz_lo elements behind); partial: advh_bn_partial_count() * 288 floats; dw: 288 floats [32][9]. */
+int advh_unet_skip_wgrad(const void* dz, int Fq, int Tq, int B, int H, int W, const float* mag, int PH, int PW, float* partial, float* dw,
+                         advh_stream_t stream);
+int advh_unet_skip_wgrad_split(const void* dz, int64_t dz_lo, int Fq, int Tq, int B, int H, int W, const float* mag, int PH, int PW,
+                               float* partial, float* dw, advh_stream_t stream);
 
 /* Weight gradient of a 3x3 stride-1 "same" Conv2d, C_in = C_out = C in {32, 64}, without transposed copies in HBM:
  * dw[kh*3+kw][co][ci] = sum_p dz[p][co] * x[p + (kh-1, kw-1)][ci].  X and DZ are zero-haloed channels-last fp16 maps of

@@ -114,6 +114,8 @@ SIGNATURES = {
     "advh_unet_head_bwd_split": (_i, [_p, _p, _p, _f, _i64, _p, _p, _i64, _p]),
     "advh_unet_head_wgrad_split": (_i, [_p, _p, _i64, _i64, _p, _p, _p]),
     "advh_unet_stem_wgrad_split": (_i, [_p, _i64, _i, _i, _i, _i, _i, _p, _i, _i, _p, _p, _p]),
+    "advh_unet_skip_wgrad": (_i, [_p, _i, _i, _i, _i, _i, _p, _i, _i, _p, _p, _p]),
+    "advh_unet_skip_wgrad_split": (_i, [_p, _i64, _i, _i, _i, _i, _i, _p, _i, _i, _p, _p, _p]),
     "advh_split_overflow": (_i, [_i]),
     "advh_resblock_pair_x3_lds_bytes": (_i, [_i, _i, _i]),
     "advh_resblock_pair_x3": (_i, [_p, _i, _p]),

@@ -266,20 +266,25 @@ class HipUNetTrain:
             L["wg2d"] = Wgrad2dDesc(B=B, H=Hd, W_=Wd, PHx=f0.PH, PWx=f0.PW, PHz=pph, PWz=ppw)
             L["wg2d_part"] = torch.empty(nparts * 9 * Cout * Cout, dtype=torch.float32, device=dev)
             return L
+        # the d1 concat map "u1" is 32 up-sampled channels + the magnitude (channel 32) + 7 zero channels: its 32-channel part is a slice like
+        # any other, the magnitude channel has its own kernel (advh_unet_skip_wgrad, reading the fp32 input directly)
+        skip_src = srcs == ["u1"] and m["u1"].C == 40 and Cout == 32
         if (plain33 and sp and Cout % 32 == 0 and pph >= 1 and ppw >= 1
-                and all(m[s_].C % 32 == 0 and m[s_].PH >= 1 and m[s_].PW >= 1 for s_ in srcs)):
+                and all((m[s_].C % 32 == 0 or skip_src) and m[s_].PH >= 1 and m[s_].PW >= 1 for s_ in srcs)):
             cuts = lambda n: [(o, 64) for o in range(0, n - n % 64, 64)] + ([(n - 32, 32)] if n % 64 else [])
             pairs, base, nmax = [], 0, 0
             for s_ in srcs:
                 f = m[s_]
                 d2 = Wgrad2dDesc(B=B, H=Hd, W_=Wd, PHx=f.PH, PWx=f.PW, PHz=pph, PWz=ppw)
-                for cx0, CI in cuts(f.C):
+                for cx0, CI in cuts(32 if skip_src else f.C):
                     for cz0, CO in cuts(Cout):
                         pairs.append((s_, d2, CI, CO, cx0, cz0, base))
                         nmax = max(nmax, _lib.lib().advh_conv_wgrad2d_split_parts(CI, CO, B, Hd, Wd) * 9 * CI * CO)
                 base += f.C
             L["wg2d_pairs"] = pairs
             L["wg2d_part"] = torch.empty(nmax, dtype=torch.float32, device=dev)
+            if skip_src:
+                L["wg2d_skip"] = torch.empty(self.nparts * 288, dtype=torch.float32, device=dev)
             return L
         # ---- wgrad: position-major operands on the common grid (dz's interior grid + vertical tap halo, width % 8 == 0)
         Hg, Wg, GH = Hd + (KH - 1) * dh, G.round_up(Wd, 8), ph
@@ -504,6 +509,12 @@ class HipUNetTrain:
                     _lib.check(lib.advh_conv_wgrad2d_split(C.byref(d2), CI, CO, xm.C, cx0, Cn, cz0, xm.t.stride(0), dzm.t.stride(0),
                                                             dw9.data_ptr(), st), "advh_conv_wgrad2d_split")
                     dwf[cz0:cz0 + CO, base + cx0:base + cx0 + CI] = dw9.view(3, 3, CO, CI).permute(2, 3, 0, 1)
+                if "wg2d_skip" in L:                                   # the magnitude channel of the d1 concat map
+                    dws = torch.empty(32, 9, dtype=torch.float32, device=self.dev)
+                    _lib.check(lib.advh_unet_skip_wgrad_split(dzm.t.data_ptr(), dzm.t.stride(0), Fq, Tq, B, H, W, mag.data_ptr(), dzm.PH, dzm.PW,
+                                                               L["wg2d_skip"].data_ptr(), dws.data_ptr(), st), "advh_unet_skip_wgrad_split")
+                    dwf[:, 33:] = 0.0
+                    dwf[:, 32] = dws.view(32, 3, 3)
                 grads[L["cname"] + ".weight"] = (dwf / S)[:, :w.shape[1]].contiguous()
             elif "wg2d" in L:
                 d2 = L["wg2d"]

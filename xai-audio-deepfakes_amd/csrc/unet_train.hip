@@ -333,6 +333,43 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const _Float16* __restr
     }
 }
 
+// weight gradient of the ONE skip channel of d1.block.0 (Conv2d(33, 32, 3, padding 1) on torch.cat([up1(y2), x], 1), addvisor.py:57-60, 79):
+// dW[co][kh*3+kw] = sum_p dz[p][co] * mag[b][h+kh-1][w+kw-1] -- the stem kernel's scheme (thread = (co, position lane), broadcast loads of
+// the magnitudes) for a 3x3 stride-1 window.  The other 32 input channels of that layer go through the LDS-tile kernel of conv_wgrad.hip;
+// before this kernel the 40-channel concat map kept the whole layer on operand transposes + a split-K GEMM (4.8 ms of the training step).
+__global__ __launch_bounds__(256) void skip_wgrad_kernel(const _Float16* __restrict__ dz, const float* __restrict__ mag, int Fq, int Tq, int B, int H,
+                                                         int W, int PH, int PW, float* __restrict__ partial /*[NPART][288]*/, long dz_lo) {
+    __shared__ float red[8][288];
+    const int co = threadIdx.x & 31, pl = threadIdx.x >> 5;
+    const long total = (long)B * H * W;
+    float acc[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) acc[k] = 0.f;
+    for (long i = (long)blockIdx.x * 8 + pl; i < total; i += (long)gridDim.x * 8) {
+        const int w = (int)(i % W);
+        const long r = i / W;
+        const int h = (int)(r % H), b = (int)(r / H);
+        const long di = (((long)b * (H + 2 * PH) + h + PH) * (W + 2 * PW) + w + PW) * 32 + co;
+        const float d = dz_lo ? join_f32(dz[di], dz[di + dz_lo]) : (float)dz[di];
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int hh = h + kh - 1, ww = w + kw - 1;
+                const float x = (hh >= 0 && hh < H && ww >= 0 && ww < W) ? mag[((long)b * Fq + hh) * Tq + ww] : 0.f;
+                acc[kh * 3 + kw] = fmaf(d, x, acc[kh * 3 + kw]);
+            }
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) red[pl][co * 9 + k] = acc[k];
+    __syncthreads();
+    for (int i = threadIdx.x; i < 288; i += 256) {
+        float a = 0.f;
+        for (int r = 0; r < 8; ++r) a += red[r][i];
+        partial[(long)blockIdx.x * 288 + i] = a;
+    }
+}
+
 }  // namespace advh
 
 using namespace advh;
@@ -370,6 +407,24 @@ extern "C" int advh_unet_stem_wgrad_split(const void* dz, int64_t dz_lo, int Fq,
                                           int PW, float* partial, float* dw, advh_stream_t stream) {
     if (dz_lo <= 0) return ADVH_EINVAL;
     return stem_wgrad_launch(dz, dz_lo, Fq, Tq, B, H, W, mag, PH, PW, partial, dw, stream);
+}
+
+static int skip_wgrad_launch(const void* dz, long dz_lo, int Fq, int Tq, int B, int H, int W, const float* mag, int PH, int PW,
+                             float* partial, float* dw, advh_stream_t stream) {
+    if (!dz || !mag || !partial || !dw || B <= 0 || H <= 0 || W <= 0 || H > Fq || W > Tq || PH < 0 || PW < 0) return ADVH_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(skip_wgrad_kernel, dim3(NPART), dim3(256), 0, s, (const _Float16*)dz, mag, Fq, Tq, B, H, W, PH, PW, partial, dz_lo);
+    hipLaunchKernelGGL(bn_reduce_kernel, dim3(72), dim3(256), 0, s, partial, NPART, 144, dw);
+    return ADVH_LAUNCH_CHECK();
+}
+extern "C" int advh_unet_skip_wgrad(const void* dz, int Fq, int Tq, int B, int H, int W, const float* mag, int PH, int PW, float* partial,
+                                    float* dw, advh_stream_t stream) {
+    return skip_wgrad_launch(dz, 0, Fq, Tq, B, H, W, mag, PH, PW, partial, dw, stream);
+}
+extern "C" int advh_unet_skip_wgrad_split(const void* dz, int64_t dz_lo, int Fq, int Tq, int B, int H, int W, const float* mag, int PH,
+                                          int PW, float* partial, float* dw, advh_stream_t stream) {
+    if (dz_lo <= 0) return ADVH_EINVAL;
+    return skip_wgrad_launch(dz, dz_lo, Fq, Tq, B, H, W, mag, PH, PW, partial, dw, stream);
 }
 
 static bool geom_ok(const advh_map_geom* g) {
