@@ -77,6 +77,9 @@ def test_argument_errors_of_the_round3_entry_points(built):
     d.PHx = 0
     assert lib.advh_conv_wgrad2d_split(C.byref(d), 32, 32, 32, 0, 32, 0, 1024, 1024, p, None) == EINVAL         # the patch needs a halo
     assert lib.advh_conv_wgrad2d_split_parts(64, 64, 64, 128, 196) == 256 and lib.advh_conv_wgrad2d_split_parts(32, 32, 1, 16, 16) == 1
+    assert lib.advh_unet_skip_wgrad_split(p, 1024, 8, 16, 1, 16, 16, p, 1, 1, p, p, None) == EINVAL      # H > Fq: the crop must lie inside the input
+    assert lib.advh_unet_skip_wgrad_split(p, 0, 16, 16, 1, 16, 16, p, 1, 1, p, p, None) == EINVAL         # no lo plane
+    assert lib.advh_unet_skip_wgrad(None, 16, 16, 1, 16, 16, p, 1, 1, p, p, None) == EINVAL
     assert lib.advh_set_option(b"attention_bwd_mfma_f32", 1) == 0 and lib.advh_set_option(b"attention_bwd_mfma_f32", 0) == 0
     assert lib.advh_set_option(b"no_such_option", 1) == EINVAL
     assert lib.advh_split_overflow(0) == 0                                                # no device initialised: no flag word, reads as clear
