@@ -459,6 +459,13 @@ typedef struct advh_taps_desc {
     int pre_act;          /* 1: LeakyReLU(pre_slope) is applied to X inside the line buffer (X is the raw map) */
     float pre_slope;
 } advh_taps_desc;
+/* The same layer in the fp32-class mode, C = 64: X, W, resid, out_h, out_h2 are split-format plane pairs (lo plane x_lo / w_lo / r_lo /
+ * o_lo elements behind the hi plane; out_h and out_h2 share o_lo), three MFMAs per fragment pair (the arithmetic of the x3 GEMM).  The weights
+ * stream tap by tap through a two-slot LDS ring (two planes of an 11-tap tensor do not fit), the line buffer is double-buffered;
+ * advh_conv_taps_split_tile(C, ntap, span) = positions per tile, 0 if the layer does not fit.  pre_act is not supported (ADVH_EUNSUPPORTED).
+ * Replaces the x3 implicit GEMM for the k = 7 / 11 ResBlock convolutions of HiFi-GAN's 64-channel stage (hifigan.py:106-110, 180).  */
+int advh_conv_taps_split_tile(int C, int ntap, int span);
+int advh_conv_taps_split(const advh_taps_desc* d, int C, int64_t x_lo, int64_t w_lo, int64_t r_lo, int64_t o_lo, advh_stream_t stream);
 /* 2-D variant: 3x3 stride-1 "same" Conv2d, C_in = C_out = C in {32, 64}, on zero-haloed NHWC fp16 maps of ONE geometry
  * [B][H+2PH][W_+2PW][C] (PH, PW >= 1) -- the second convolution of the U-Net's 32- / 64-channel ConvBlocks
  * (addvisor.py:20-24 with BatchNorm folded).  16 x 16 output tiles with an 18 x 18 line-buffer patch; W [9][C_out][C_in]

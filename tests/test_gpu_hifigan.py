@@ -127,3 +127,33 @@ def test_v1_f32_fused_resblock_matches_unfused(gpu_device):
     assert err <= 2e-6
     assert (a.cpu() - ref).abs().max().item() <= 1e-4
     assert torch.equal(fused.decode_batch(mel[1:2].to(gpu_device))[0], a[1])          # batch invariance
+
+
+@pytest.mark.parametrize("k,dil,B,T", [(7, 3, 3, 700), (11, 5, 2, 1000), (11, 1, 1, 255), (7, 1, 5, 64)])
+def test_split_line_tile_matches_implicit_gemm(gpu_device, k, dil, B, T):
+    """``advh_conv_taps_split`` (64 channels, weights streamed tap by tap through an LDS ring, eight wavefronts) against the x3 implicit
+    GEMM on the same split-format maps: both ResBlock roles -- conv1 (bias + LeakyReLU) and conv2 (bias + residual, raw and pre-activated
+    outputs) -- with clips shorter and longer than a 256-position tile; same three-MFMA arithmetic in the same K order."""
+    from addvisor_hip import gemm as G
+    g = torch.Generator().manual_seed(100 * k + dil)
+    halo = 32
+    maps = [G.Map1D(B, T, 64, halo, split=True).alloc(gpu_device) for _ in range(8)]
+    src, res, o1, o2, p1, p2, q1, q2 = maps
+    for m_ in (src, res):
+        m_.t[:, :, halo:halo + T] = G.split_planes(torch.randn(B, T, 64, generator=g)).to(gpu_device)
+    w = torch.randn(64, 64, k, generator=g) * (0.3 / k ** 0.5)
+    b = torch.randn(64, generator=g) * 0.1
+    assert G.taps_split_supported(src, o1, w, dil)
+    # conv1 role
+    G.plan_conv1d_taps(src, o1, w, b, dilation=dil, act="leaky", slope=0.1, device=gpu_device).run(src.t, out_h=o1.t)
+    G.plan_conv1d_same(src, o2, w, b, dilation=dil, act="leaky", slope=0.1, device=gpu_device).run(src.t, out_h=o2.t)
+    # conv2 role
+    G.plan_conv1d_taps(src, p1, w, b, dilation=dil, slope2=0.1, device=gpu_device).run(src.t, out_h=p1.t, resid=res.t, out_h2=q1.t)
+    G.plan_conv1d_same(src, p2, w, b, dilation=dil, slope2=0.1, device=gpu_device).run(src.t, out_h=p2.t, resid=res.t, out_h2=q2.t)
+    torch.cuda.synchronize()
+    for name, a_, b_ in (("conv1", o1, o2), ("conv2", p1, p2), ("conv2 pre-activated copy", q1, q2)):
+        ja, jb = G.join_planes(a_.t.cpu()), G.join_planes(b_.t.cpu())
+        err = float((ja - jb).abs().max() / jb.abs().max())
+        print(f"split line tile vs implicit GEMM, k={k} d={dil} {name}: {err:.2e}")
+        assert err <= 1e-6, name
+        assert float(ja[:, :halo].abs().max()) == 0.0 and float(ja[:, halo + T:].abs().max()) == 0.0      # the halo stays zero

@@ -90,6 +90,8 @@ SIGNATURES = {
     "advh_conv_taps_tile": (_i, [_i, _i, _i]),
     "advh_conv_taps_lds_bytes": (_i, [_i, _i, _i]),
     "advh_conv_taps_f16": (_i, [_p, _i, _p]),
+    "advh_conv_taps_split_tile": (_i, [_i, _i, _i]),
+    "advh_conv_taps_split": (_i, [_p, _i, _i64, _i64, _i64, _i64, _p]),
     "advh_conv_taps2d_f16": (_i, [_p, _i, _p]),
     "advh_upconv21_tile_f16": (_i, [_p, _p]),
     "advh_posconv_tile_f16": (_i, [_p, _p]),

@@ -861,12 +861,19 @@ class TapsPlan:
 
     def __init__(self, *, M: int, Cn: int, w_taps: torch.Tensor, toff: Sequence[int], Hg: int, Wg: int,
                  window: Tuple[int, int, int, int], bias: Optional[torch.Tensor], act: str = "none",
-                 slope: float = 0.0, slope2: float = 0.0, device=None, pre_slope: Optional[float] = None):
+                 slope: float = 0.0, slope2: float = 0.0, device=None, pre_slope: Optional[float] = None, split: bool = False):
+        """``split``: the fp32-class form (``advh_conv_taps_split``: every map and the weights are split-format plane pairs, the weights
+        stream through LDS tap by tap; 64 channels, no ``pre_slope``)."""
         ntap = len(toff)
         assert w_taps.shape == (ntap, Cn, Cn) and Cn in (32, 64) and 0 < ntap <= 16
-        assert taps_tile(Cn, ntap, max(max(toff), 0) - min(min(toff), 0)) > 0
+        span = max(max(toff), 0) - min(min(toff), 0)
+        self.split = split
+        if split:
+            assert pre_slope is None and taps_split_tile(Cn, ntap, span) > 0
+        else:
+            assert taps_tile(Cn, ntap, span) > 0
         self.Cn, self.device = Cn, device
-        self.w = w_taps.to(torch.float16).contiguous()
+        self.w = split_planes(w_taps.double()).contiguous() if split else w_taps.to(torch.float16).contiguous()     # [2, ntap, C, C] | [ntap, C, C]
         self.bias = None if bias is None else bias.to(torch.float32).contiguous()
         if device is not None:
             self.w = self.w.to(device)
@@ -886,8 +893,9 @@ class TapsPlan:
     def run(self, A0: torch.Tensor, A1=None, *, out_h: torch.Tensor, resid: Optional[torch.Tensor] = None,
             out_h2: Optional[torch.Tensor] = None, stream: Optional[int] = None):
         d = self.desc
+        planes = 2 if self.split else 1
         for t in (A0, out_h, resid, out_h2):
-            assert t is None or (t.dtype == torch.float16 and t.is_cuda and t.numel() == d.M * self.Cn and t.is_contiguous())
+            assert t is None or (t.dtype == torch.float16 and t.is_cuda and t.numel() == planes * d.M * self.Cn and t.is_contiguous())
         d.X, d.W = A0.data_ptr(), self.w.data_ptr()
         d.bias = self.bias.data_ptr() if self.bias is not None else None
         d.resid = resid.data_ptr() if resid is not None else None
@@ -895,7 +903,12 @@ class TapsPlan:
         d.out_h2 = out_h2.data_ptr() if out_h2 is not None else None
         if stream is None:
             stream = torch.cuda.current_stream().cuda_stream
-        _lib.check(_lib.lib().advh_conv_taps_f16(C.byref(d), self.Cn, stream), "advh_conv_taps_f16")
+        if self.split:
+            n = d.M * self.Cn                                    # plane pairs [2, M, C]: the lo plane one plane behind
+            _lib.check(_lib.lib().advh_conv_taps_split(C.byref(d), self.Cn, n, self.w.stride(0), n if resid is not None else 0, n, stream),
+                       "advh_conv_taps_split")
+        else:
+            _lib.check(_lib.lib().advh_conv_taps_f16(C.byref(d), self.Cn, stream), "advh_conv_taps_f16")
 
 
 class Taps2dDesc(C.Structure):
@@ -1057,6 +1070,21 @@ class ResblockPairX3Plan:
         _lib.check(_lib.lib().advh_resblock_pair_x3(C.byref(d), self.Cn, stream), "advh_resblock_pair_x3")
 
 
+def taps_split_tile(Cn: int, ntap: int, span: int) -> int:
+    """Host copy of ``advh_conv_taps_split_tile``: positions per tile of the fp32-class 64-channel kernel (four weight slots and one line buffer, two planes each, in 160 KiB); 0 = unsupported."""
+    if Cn != 64 or not 0 < ntap <= 16:
+        return 0
+    return 256 if 4 * 2 * 64 * 64 * 2 + 2 * (((256 + span) * 8 + 63) // 64 * 64) * 16 <= 160 * 1024 else 0
+
+
+def taps_split_supported(src: Map1D, dst: Map1D, weight: torch.Tensor, dilation: int) -> bool:
+    """Layers the split-arithmetic line-tile kernel takes AND wins on: 64 channels in and out, k >= 7 (the k = 3 layers are HBM-bound on
+    their 4-byte maps either way and stay on the implicit GEMM)."""
+    Cout, Cin, k = weight.shape
+    return (src.split and dst.split and Cout == Cin == 64 and src.C == 64 and dst.C == 64 and src.halo == dst.halo and 7 <= k <= 16
+            and taps_split_tile(64, k, (k - 1) * dilation) > 0)
+
+
 def taps_supported(src: Map1D, dst: Map1D, weight: torch.Tensor, dilation: int) -> bool:
     Cout, Cin, k = weight.shape
     return (Cout == Cin and Cin in (32, 64) and src.C == Cin and dst.C == Cout and src.halo == dst.halo and k <= 16
@@ -1070,11 +1098,12 @@ def plan_conv1d_taps(src: Map1D, dst: Map1D, weight: torch.Tensor, bias: Optiona
     ``pre_slope`` the input map is the RAW map and LeakyReLU(pre_slope) is applied inside the line buffer."""
     Cout, Cin, k = weight.shape
     pad = (k - 1) * dilation // 2
-    assert taps_supported(src, dst, weight, dilation) and src.halo >= pad and (src.B, src.T) == (dst.B, dst.T)
+    split = bool(src.split)
+    assert (taps_split_supported if split else taps_supported)(src, dst, weight, dilation) and src.halo >= pad and (src.B, src.T) == (dst.B, dst.T)
     toff = [j * dilation - pad for j in range(k)]
     return TapsPlan(M=dst.B * dst.P, Cn=Cin, w_taps=weight.permute(2, 0, 1).float(), toff=toff, Hg=1, Wg=dst.P,
                     window=(0, 1, dst.halo, dst.halo + dst.T), bias=bias, act=act, slope=slope, slope2=slope2,
-                    device=device, pre_slope=pre_slope)
+                    device=device, pre_slope=pre_slope, split=split)
 
 
 def replay_taps_on_cpu(plan: TapsPlan, X: torch.Tensor, resid: Optional[torch.Tensor] = None) -> torch.Tensor:

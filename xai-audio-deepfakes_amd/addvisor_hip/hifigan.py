@@ -42,8 +42,8 @@ class HipHifigan:
         if precision not in ("f16", "f32"):
             raise ValueError("precision must be 'f16' or 'f32'")
         self.precision, self.split = precision, precision == "f32"
-        # fp32-class mode: the 32-channel ResBlock steps have a fused split-format kernel (csrc/resblock_pair_x3.hip); the other
-        # line-tile kernels are fp16-only, those layers run the x3 implicit GEMM
+        # fp32-class mode: the 32-channel ResBlock steps have a fused split-format kernel (csrc/resblock_pair_x3.hip), the k >= 7 convolutions
+        # of the 64-channel stage a split-format line tile with streamed weights (csrc/conv_taps.hip); the other layers run the x3 implicit GEMM
         self.fuse_x3 = self.split and fuse and padding_mode == "zeros"
         if self.split:
             line_tile = fuse = False
@@ -84,6 +84,8 @@ class HipHifigan:
         def conv(src, dst, w, b, **kw):
             if self.line_tile and G.taps_supported(src, dst, w, kw.get("dilation", 1)):
                 return G.plan_conv1d_taps(src, dst, w, b, device=dev, **kw)
+            if self.fuse_x3 and G.taps_split_supported(src, dst, w, kw.get("dilation", 1)) and kw.get("pre_slope") is None:
+                return G.plan_conv1d_taps(src, dst, w, b, device=dev, **kw)       # fp32-class line tile with streamed weights (64 channels, k >= 7)
             if kw.pop("pre_slope", None) is not None:
                 raise RuntimeError("a layer of a line-buffer-activated stage does not fit the line-tile kernel")
             return G.plan_conv1d_same(src, dst, w, b, device=dev, **kw)

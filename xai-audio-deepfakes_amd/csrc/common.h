@@ -11,6 +11,7 @@ int advh_split_flag_attention(int* flag);
 int advh_split_flag_attention_bwd_f32(int* flag);
 int advh_split_flag_attention_bwd_x3(int* flag);
 int advh_split_flag_backward(int* flag);
+int advh_split_flag_conv_taps(int* flag);
 int advh_split_flag_frontend(int* flag);
 int advh_split_flag_frontend_bwd(int* flag);
 int advh_split_flag_gemm(int* flag);

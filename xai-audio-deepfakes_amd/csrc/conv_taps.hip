@@ -13,6 +13,7 @@
 #include <hip/hip_fp16.h>
 #include "addvisor_hip.h"
 #include "common.h"
+#include "device_math.h"
 
 namespace advh {
 
@@ -322,6 +323,181 @@ __global__ __launch_bounds__(64 * NW) void conv_taps2d_kernel(const advh_taps2d_
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// ---------------------------------------------------------------------------------------------------
+// fp32-class form for the 64-channel stage (round 3): X, W, resid, out_h, out_h2 are split-format plane pairs (hi plane, lo plane a fixed
+// distance behind: advh_conv_taps_split's *_lo), every fragment pair costs three MFMAs in the order of gemm_x3_kernel (accx += Wh Xl;
+// acc += Wh Xh; accx += Wl Xh; result acc + accx * 2^-11) and the K order is the GEMM's (tap-major, two 32-deep steps per tap): the outputs
+// are bit-identical to the x3 implicit GEMM's (tests/test_gpu_hifigan.py).  Two planes of an 11-tap 64 x 64 weight tensor are 180 KiB, so the
+// weights are NOT resident: they stream tap by tap (16 KiB per tap, both planes) through a four-slot LDS ring, tap n + 3 requested when tap n
+// starts (an LDS DMA takes ~1 700 cycles from issue to landing); ONE line buffer (256 positions + halo, both planes): the next tile's lines are
+// requested after the last tap and land under the epilogue.  Eight wavefronts of 64 channels x 32 positions (64 accumulator registers, two
+// wavefronts per SIMD): the kernel is LDS-bandwidth-bound by construction -- 12 KiB of fragments per 24 MFMAs and wavefront = 125 B/clk per CU
+// at full matrix rate -- and reaches 280 - 327 TFLOP/s on the k = 7 / 11 ResBlock convolutions of HiFi-GAN's 64-channel stage against 240 - 287
+// for the x3 implicit GEMM on 256 x 64 tiles (which re-reads the input once per tap through the L2 -> LDS path); with four wavefronts of
+// 64 x 64 (one per SIMD, nothing to cover LDS time and the per-tap barrier with) it ran level with the GEMM: profiles/r03_conv_taps_x3_experiment.txt.
+template <int NJ, int NW>
+__global__ __launch_bounds__(64 * NW) void conv_taps_x3_kernel(const advh_taps_desc p, long x_lo, long w_lo, long r_lo, long o_lo) {
+    constexpr int C = 64, CH = 8, CT = 4, KS = 2, TT = 16 * NJ * NW, NTH = 64 * NW, WTAP = C * C * 2, WPT = 2 * (C * CH / NTH);   // WPT: DMA instructions per thread and tap     // WTAP: bytes of one plane of one tap
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int fr = lane & 15, g = lane >> 4;
+    int lo = 0, hi = 0;
+    for (int t = 0; t < p.ntap; ++t) { lo = min(lo, p.toff[t]); hi = max(hi, p.toff[t]); }
+    const int SR = TT + hi - lo;                                   // line-buffer rows
+    const int SRC = (SR * CH + 63) & ~63;                          // chunks per plane and buffer (whole wave loads)
+    constexpr int NSLOT = 4, AHEAD = NSLOT - 1;                    // weight ring: tap n + 3 is requested when tap n starts
+    char* Wl = lds;                                                // NSLOT slots x [hi | lo] x [C][C] halfs
+    char* Xl = lds + NSLOT * 2 * WTAP;                             // [hi | lo] x [SR][C] halfs (one buffer: the next tile's lines are requested
+                                                                   // when the last tap's MFMAs are done and arrive under the epilogue)
+    const _Float16* Wg = (const _Float16*)p.W;
+    const _Float16* X = (const _Float16*)p.X;
+    const int ntiles = (p.M + TT - 1) / TT;
+    auto load_weights = [&](int t, int slot) {
+        char* dst = Wl + (size_t)slot * 2 * WTAP;
+        for (int i = tid; i < C * CH; i += NTH) {                  // i = lds chunk index (wave-linear): row = output-channel slot, pos = chunk
+            const int row = i / CH, pos = i % CH;
+            const _Float16* src = Wg + ((long)t * C + cout_of(row)) * C + ((pos ^ swz<C>(row)) * 8);
+            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src), LDS_PTR(dst + (size_t)(i - lane) * 16), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src + w_lo), LDS_PTR(dst + WTAP + (size_t)(i - lane) * 16), 16, 0, 0);
+        }
+    };
+    auto load_lines = [&](int tile) {                              // rows p0+lo .. p0+TT+hi, clamped: rows outside the map only feed halo outputs
+        const long p0 = (long)tile * TT + lo;
+        char* dst = Xl;
+        for (int i = tid; i < SRC; i += NTH) {
+            int row = i / CH, pos = i % CH;
+            long r = p0 + row;
+            r = r < 0 ? 0 : (r >= p.M ? p.M - 1 : r);
+            const _Float16* src = X + r * C + ((pos ^ swz<C>(row)) * 8);
+            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src), LDS_PTR(dst + (size_t)(i - lane) * 16), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src + x_lo), LDS_PTR(dst + (size_t)SRC * 16 + (size_t)(i - lane) * 16), 16, 0, 0);
+        }
+    };
+    float4 bias[CT];                                               // bias[2q + e] = channels 32 q + 8 g + 4 e .. + 3
+#pragma unroll
+    for (int i = 0; i < CT; ++i)
+        bias[i] = p.bias ? *(const float4*)(p.bias + (i >> 1) * 32 + g * 8 + (i & 1) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    int toffv = 0;                                                 // lane t holds toff[t]
+#pragma unroll
+    for (int t = 0; t < 16; ++t) toffv = (lane == t) ? p.toff[t] : toffv;
+
+    // global tap counter n (tap n % ntap of the workgroup's n / ntap-th tile) lives in slot n % NSLOT; taps 0 .. AHEAD-1 and the first lines up front
+    const int mytiles = (int)blockIdx.x < ntiles ? (ntiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    const int ntot = mytiles * p.ntap;
+    for (int n = 0; n < AHEAD && n < ntot; ++n) load_weights(n % p.ntap, n % NSLOT);
+    if (mytiles) load_lines(blockIdx.x);
+    int n = 0;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long p0 = (long)tile * TT;
+        f32x4 acc[CT][NJ], accx[CT][NJ];
+#pragma unroll
+        for (int i = 0; i < CT; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) { acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; accx[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        const char* xb = Xl;
+        // Fragment pipeline (one wavefront per SIMD: nothing else hides LDS time): the 16 ds_read_b128 of the NEXT 32-deep step are issued before
+        // the 48 MFMAs of the current one.  The step after a tap's second one belongs to the next tap, so the barrier at the top of tap n
+        // already covers the weights of tap n + 1 (requested three taps ago); tap n + 3 is requested right after it.
+        f16x8 fwh[2][CT], fwl[2][CT], fxh[2][NJ], fxl[2][NJ];
+        auto fetch = [&](int set, int nn, int tt, int ks) {
+            const char* wb = Wl + (size_t)(nn % NSLOT) * 2 * WTAP;
+            const int rowb = wv * (16 * NJ) + fr + __builtin_amdgcn_readlane(toffv, tt) - lo;
+            const int c = ks * 4 + g;
+#pragma unroll
+            for (int i = 0; i < CT; ++i) {
+                const int wo = ((i * 16 + fr) * CH + (c ^ swz<C>(fr))) * 16;             // (16 i + fr) & 7 == fr & 7
+                fwh[set][i] = *(const f16x8*)(wb + wo);
+                fwl[set][i] = *(const f16x8*)(wb + WTAP + wo);
+            }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int row = rowb + j * 16;
+                const int xo = (row * CH + (c ^ swz<C>(row))) * 16;
+                fxh[set][j] = *(const f16x8*)(xb + xo);
+                fxl[set][j] = *(const f16x8*)(xb + (size_t)SRC * 16 + xo);
+            }
+        };
+        auto mma = [&](int set) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+                for (int i = 0; i < CT; ++i) accx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fwh[set][i], fxl[set][j], accx[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < CT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fwh[set][i], fxh[set][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < CT; ++i) accx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fwl[set][i], fxh[set][j], accx[i][j], 0, 0, 0);
+            }
+        };
+        for (int t = 0; t < p.ntap; ++t, ++n) {
+            // t = 0: the tile's lines, the previous epilogue's stores and taps n, n + 1 must have landed (everything); later: all but the 4 DMA
+            // instructions per thread of the youngest requested tap (n + 2)
+            if (t == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPT) : "memory");
+            __syncthreads();                                       // ... everyone's pieces; every wavefront is done with tap n - 1 (its slot is free)
+            if (n + AHEAD < ntot) load_weights((n + AHEAD) % p.ntap, (n + AHEAD) % NSLOT);
+            if (t == 0) fetch(0, n, 0, 0);
+            fetch(1, n, t, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + 1 < p.ntap) fetch(0, n + 1, t + 1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (tile + (int)gridDim.x < ntiles) {
+            __syncthreads();                                       // every wavefront has read its last fragments of this tile's lines
+            load_lines(tile + gridDim.x);
+        }
+        // ---- epilogue: bias, LeakyReLU, residual, split stores (and the pre-activated copy)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const long pos = p0 + wv * (16 * NJ) + j * 16 + fr;
+            if (pos >= p.M) continue;
+            unsigned w = (unsigned)(pos % p.Wg), tq = (unsigned)(pos / p.Wg);
+            unsigned h = tq % (unsigned)p.Hg;
+            const bool ok = (int)h >= p.h0 && (int)h < p.h1 && (int)w >= p.w0 && (int)w < p.w1;
+#pragma unroll
+            for (int q = 0; q < CT / 2; ++q) {
+                const long o = pos * C + q * 32 + g * 8;
+                float v[8];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v[r] = fmaf(accx[2 * q][j][r], SPLIT_LO_INV, acc[2 * q][j][r]);
+                    v[4 + r] = fmaf(accx[2 * q + 1][j][r], SPLIT_LO_INV, acc[2 * q + 1][j][r]);
+                }
+                if (ok) {
+                    v[0] += bias[2 * q].x; v[1] += bias[2 * q].y; v[2] += bias[2 * q].z; v[3] += bias[2 * q].w;
+                    v[4] += bias[2 * q + 1].x; v[5] += bias[2 * q + 1].y; v[6] += bias[2 * q + 1].z; v[7] += bias[2 * q + 1].w;
+                    if (p.act == ADVH_ACT_LEAKY) {
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) v[r] = v[r] > 0.f ? v[r] : p.slope * v[r];
+                    }
+                    if (p.resid) {
+                        float rr[8];
+                        load_h_rt<8>((const _Float16*)p.resid, o, r_lo, rr);
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) v[r] += rr[r];
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) v[r] = 0.f;
+                }
+                store_h_rt<8>((_Float16*)p.out_h, o, o_lo, v);
+                if (p.out_h2) {
+                    float v2[8];
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) v2[r] = v[r] > 0.f ? v[r] : p.slope2 * v[r];
+                    store_h_rt<8>((_Float16*)p.out_h2, o, o_lo, v2);
+                }
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+static int taps_x3_lds(int span, int nj) { return 4 * 2 * 64 * 64 * 2 + 2 * ((((64 * nj + span) * 8 + 63) / 64 * 64) * 16); }   // 4 weight slots + one line buffer, two planes each
+
 static int taps_span(const advh_taps_desc* d) {
     int lo = 0, hi = 0;
     for (int t = 0; t < d->ntap; ++t) { lo = d->toff[t] < lo ? d->toff[t] : lo; hi = d->toff[t] > hi ? d->toff[t] : hi; }
@@ -385,3 +561,30 @@ extern "C" int advh_conv_taps2d_f16(const advh_taps2d_desc* d, int C, advh_strea
     else hipLaunchKernelGGL(conv_taps2d_kernel<32>, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, *d);
     return ADVH_LAUNCH_CHECK();
 }
+
+// column tiles of the split-arithmetic 64-channel kernel: 4 (256 positions per tile) where weights ring + two line buffers fit, else 3
+extern "C" int advh_conv_taps_split_tile(int C, int ntap, int span) {
+    if (C != 64 || ntap <= 0 || ntap > 16 || span < 0) return 0;
+    return taps_x3_lds(span, 4) <= 160 * 1024 ? 256 : 0;
+}
+
+extern "C" int advh_conv_taps_split(const advh_taps_desc* d, int C, int64_t x_lo, int64_t w_lo, int64_t r_lo, int64_t o_lo, advh_stream_t stream) {
+    if (!d || !d->X || !d->W || !d->out_h || d->M <= 0 || d->ntap <= 0 || d->ntap > 16 || d->Hg <= 0 || d->Wg <= 0) return ADVH_EINVAL;
+    if (x_lo <= 0 || w_lo <= 0 || o_lo <= 0 || (d->resid && r_lo <= 0) || x_lo % 8 || w_lo % 8 || o_lo % 8 || r_lo % 8) return ADVH_EINVAL;
+    if (C != 64 || d->pre_act) return ADVH_EUNSUPPORTED;
+    if (d->act != ADVH_ACT_NONE && d->act != ADVH_ACT_LEAKY) return ADVH_EINVAL;
+    const int span = taps_span(d);
+    const int tt = advh_conv_taps_split_tile(C, d->ntap, span);
+    if (!tt) return ADVH_EUNSUPPORTED;
+    const int lds = taps_x3_lds(span, 4);
+    // eight wavefronts of 64 channels x 32 positions: two per SIMD (64 accumulator registers each) cover each other's LDS and barrier time --
+    // with four wavefronts of 64 x 64 (one per SIMD) the kernel ran level with the implicit GEMM (profiles/r03_conv_taps_x3_experiment.txt)
+    const void* fn = (const void*)conv_taps_x3_kernel<2, 8>;
+    if (advh_ensure_lds(fn) != ADVH_OK) return ADVH_ELAUNCH;
+    const int ntiles = (d->M + tt - 1) / tt;
+    const int grid = ntiles < 256 ? ntiles : 256;
+    hipLaunchKernelGGL((conv_taps_x3_kernel<2, 8>), dim3(grid), dim3(512), lds, (hipStream_t)stream, *d, (long)x_lo, (long)w_lo, (long)r_lo, (long)o_lo);
+    return ADVH_LAUNCH_CHECK();
+}
+
+ADVH_SPLIT_FLAG_SETTER(advh_split_flag_conv_taps)

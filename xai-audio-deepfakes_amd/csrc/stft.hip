@@ -508,7 +508,7 @@ extern "C" int advh_init(void) {
     }
     int* dflag = nullptr;
     if (hipHostGetDevicePointer((void**)&dflag, g_split_flag_host, 0) != hipSuccess) return ADVH_ELAUNCH;
-    int (*const setters[])(int*) = {advh_split_flag_attention, advh_split_flag_attention_bwd_f32, advh_split_flag_attention_bwd_x3, advh_split_flag_backward, advh_split_flag_frontend, advh_split_flag_frontend_bwd, advh_split_flag_gemm, advh_split_flag_hifigan, advh_split_flag_rowops, advh_split_flag_unet_misc, advh_split_flag_unet_train, advh_split_flag_resblock_pair_x3};
+    int (*const setters[])(int*) = {advh_split_flag_attention, advh_split_flag_attention_bwd_f32, advh_split_flag_attention_bwd_x3, advh_split_flag_backward, advh_split_flag_conv_taps, advh_split_flag_frontend, advh_split_flag_frontend_bwd, advh_split_flag_gemm, advh_split_flag_hifigan, advh_split_flag_rowops, advh_split_flag_unet_misc, advh_split_flag_unet_train, advh_split_flag_resblock_pair_x3};
     for (auto set : setters)
         if ((rc = set(dflag)) != ADVH_OK) return rc;
     g_init_done[dev] = true;
