@@ -129,7 +129,7 @@ def test_v1_f32_fused_resblock_matches_unfused(gpu_device):
     assert torch.equal(fused.decode_batch(mel[1:2].to(gpu_device))[0], a[1])          # batch invariance
 
 
-@pytest.mark.parametrize("k,dil,B,T", [(7, 3, 3, 700), (11, 5, 2, 1000), (11, 1, 1, 255), (7, 1, 5, 64)])
+@pytest.mark.parametrize("k,dil,B,T", [(7, 3, 3, 700), (11, 5, 2, 1000), (11, 1, 1, 255), (7, 1, 5, 64), (3, 5, 2, 300)])
 def test_split_line_tile_matches_implicit_gemm(gpu_device, k, dil, B, T):
     """``advh_conv_taps_split`` (64 channels, weights streamed tap by tap through an LDS ring, eight wavefronts) against the x3 implicit
     GEMM on the same split-format maps: both ResBlock roles -- conv1 (bias + LeakyReLU) and conv2 (bias + residual, raw and pre-activated
@@ -143,7 +143,7 @@ def test_split_line_tile_matches_implicit_gemm(gpu_device, k, dil, B, T):
         m_.t[:, :, halo:halo + T] = G.split_planes(torch.randn(B, T, 64, generator=g)).to(gpu_device)
     w = torch.randn(64, 64, k, generator=g) * (0.3 / k ** 0.5)
     b = torch.randn(64, generator=g) * 0.1
-    assert G.taps_split_supported(src, o1, w, dil)
+    assert G.taps_split_supported(src, o1, w, dil, min_k=3)
     # conv1 role
     G.plan_conv1d_taps(src, o1, w, b, dilation=dil, act="leaky", slope=0.1, device=gpu_device).run(src.t, out_h=o1.t)
     G.plan_conv1d_same(src, o2, w, b, dilation=dil, act="leaky", slope=0.1, device=gpu_device).run(src.t, out_h=o2.t)

@@ -84,8 +84,9 @@ class HipHifigan:
         def conv(src, dst, w, b, **kw):
             if self.line_tile and G.taps_supported(src, dst, w, kw.get("dilation", 1)):
                 return G.plan_conv1d_taps(src, dst, w, b, device=dev, **kw)
-            if self.fuse_x3 and G.taps_split_supported(src, dst, w, kw.get("dilation", 1)) and kw.get("pre_slope") is None:
-                return G.plan_conv1d_taps(src, dst, w, b, device=dev, **kw)       # fp32-class line tile with streamed weights (64 channels, k >= 7)
+            if (self.fuse_x3 and kw.get("pre_slope") is None
+                    and G.taps_split_supported(src, dst, w, kw.get("dilation", 1), min_k=3 if kw.get("act") == "leaky" else 7)):
+                return G.plan_conv1d_taps(src, dst, w, b, device=dev, **kw)       # fp32-class line tile with streamed weights (64 channels; first convolutions k >= 3, second ones k >= 7)
             if kw.pop("pre_slope", None) is not None:
                 raise RuntimeError("a layer of a line-buffer-activated stage does not fit the line-tile kernel")
             return G.plan_conv1d_same(src, dst, w, b, device=dev, **kw)
