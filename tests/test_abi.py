@@ -77,6 +77,14 @@ def test_argument_errors_of_the_round3_entry_points(built):
     d.PHx = 0
     assert lib.advh_conv_wgrad2d_split(C.byref(d), 32, 32, 32, 0, 32, 0, 1024, 1024, p, None) == EINVAL         # the patch needs a halo
     assert lib.advh_conv_wgrad2d_split_parts(64, 64, 64, 128, 196) == 256 and lib.advh_conv_wgrad2d_split_parts(32, 32, 1, 16, 16) == 1
+    from addvisor_hip.gemm import TapsDesc, taps_split_tile
+    td = TapsDesc()
+    td.X, td.W, td.out_h, td.M, td.Hg, td.Wg, td.h0, td.h1, td.w0, td.w1, td.ntap = p, p, p, 64, 1, 64, 0, 1, 0, 64, 3
+    assert lib.advh_conv_taps_split(C.byref(td), 32, 4096, 4096, 0, 4096, None) == EUNSUPPORTED       # 64 channels only
+    assert lib.advh_conv_taps_split(C.byref(td), 64, 0, 4096, 0, 4096, None) == EINVAL                # no lo plane
+    td.pre_act = 1
+    assert lib.advh_conv_taps_split(C.byref(td), 64, 4096, 4096, 0, 4096, None) == EUNSUPPORTED       # no in-buffer activation in this form
+    assert lib.advh_conv_taps_split_tile(64, 11, 50) == taps_split_tile(64, 11, 50) == 256 and lib.advh_conv_taps_split_tile(32, 3, 2) == 0
     assert lib.advh_unet_skip_wgrad_split(p, 1024, 8, 16, 1, 16, 16, p, 1, 1, p, p, None) == EINVAL      # H > Fq: the crop must lie inside the input
     assert lib.advh_unet_skip_wgrad_split(p, 0, 16, 16, 1, 16, 16, p, 1, 1, p, p, None) == EINVAL         # no lo plane
     assert lib.advh_unet_skip_wgrad(None, 16, 16, 1, 16, 16, p, 1, 1, p, p, None) == EINVAL
