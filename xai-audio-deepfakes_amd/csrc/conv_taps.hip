@@ -433,7 +433,9 @@ __global__ __launch_bounds__(64 * NW) void conv_taps_x3_kernel(const advh_taps_d
             // instructions per thread of the youngest requested tap (n + 2)
             if (t == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPT) : "memory");
-            __syncthreads();                                       // ... everyone's pieces; every wavefront is done with tap n - 1 (its slot is free)
+            __syncthreads();                                       // ... everyone's pieces; every wavefront is done with tap n - 1 (its slot is free).
+            // (The fence of __syncthreads() makes the compiler wait vmcnt(0) here, i.e. for the younger taps' pieces too; a counted wait + bare
+            // s_barrier keeps them in flight but measured no faster -- the pieces are L2 hits that land well inside a tap -- so the fenced form stays.)
             if (n + AHEAD < ntot) load_weights((n + AHEAD) % p.ntap, (n + AHEAD) % NSLOT);
             if (t == 0) fetch(0, n, 0, 0);
             fetch(1, n, t, 1);
